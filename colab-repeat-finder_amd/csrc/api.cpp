@@ -1,0 +1,406 @@
+// api.cpp -- the C ABI of libprf (include/prf.h): contexts, genome residency, scan orchestration.
+//
+// Host-side shape of one scan (what replaces the body of the reference's detect_repeats(),
+// perfect_repeat_finder.py:33-81):
+//   memset counters -> phase 1 kernel(s) (candidates) -> phase 2 kernel (verify + filters + rows)
+//   -> copy back two counters -> (grow buffers and repeat on overflow) -> copy rows back, sort by
+//   (contig, start, end) as the reference sorts its dict (:81).
+// Everything runs on the context's own HIP stream; timings are HIP events on that stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/prf.h"
+#include "prf_host.h"
+#include "scan_vertical.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? PRF_ENOMEM : PRF_EHIP, "%s failed: %s (%s:%d)", #expr,    \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                           \
+    } while (0)
+
+struct prf_ctx {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    u64 *d_counters = nullptr;
+    u64 *h_counters = nullptr;  // pinned
+    u64 *d_cand = nullptr;
+    u64 cand_cap = 0;
+    prf_hit_dev *d_hits = nullptr;
+    u64 hit_cap = 0;
+    u32 *d_slab_counts = nullptr;  // vertical path: per (tile, wave) candidate counts
+    u64 *d_slabs = nullptr;
+    u64 slab_units = 0;            // number of (tile, wave) slabs allocated
+    u32 slab_cap = 0;              // records per slab
+};
+
+struct prf_genome {
+    prf_ctx *ctx = nullptr;
+    std::vector<u64> base, len;
+    u64 positions = 0;   // sum of contig lengths
+    u64 G = 0;           // positions in the global coordinate space incl. gaps and the sentinel tile
+    u64 nwords = 0;      // G / 64
+    u64 padw = 0;        // readable words past nwords in every linear plane
+    u32 kmax_hint = 0;
+    u64 *H = nullptr, *L = nullptr, *X = nullptr;
+    u64 *d_base = nullptr;
+    prf_vplanes vp;      // bit-sliced copy for scan_vertical
+};
+
+extern "C" {
+
+int prf_abi_version(void) { return PRF_ABI_VERSION; }
+
+const char *prf_last_error(void) { return g_err.c_str(); }
+
+int prf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int prf_open(int device_id, prf_ctx **out) {
+    if (!out) return fail(PRF_EINVAL, "prf_open: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PRF_ENODEV, "prf_open: no HIP device visible (%s); libprf has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(PRF_EINVAL, "prf_open: device %d out of range [0,%d)", device_id, n);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PRF_ENODEV, "prf_open: device %d is %s; libprf is built for gfx950 (MI355X) only", device_id,
+                    prop.gcnArchName);
+    HIPCHK(hipSetDevice(device_id));
+    prf_ctx *c = new (std::nothrow) prf_ctx();
+    if (!c) return fail(PRF_ENOMEM, "prf_open: out of host memory");
+    c->dev = device_id;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipMalloc((void **)&c->d_counters, PRF_CNT_N * sizeof(u64)));
+    HIPCHK(hipHostMalloc((void **)&c->h_counters, PRF_CNT_N * sizeof(u64), hipHostMallocDefault));
+    *out = c;
+    return PRF_OK;
+}
+
+void prf_close(prf_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_counters);
+    (void)hipHostFree(c->h_counters);
+    (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_hits);
+    (void)hipFree(c->d_slab_counts);
+    (void)hipFree(c->d_slabs);
+    for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void prf_genome_free(prf_genome *g) {
+    if (!g) return;
+    if (g->ctx) (void)hipSetDevice(g->ctx->dev);
+    (void)hipFree(g->H);
+    (void)hipFree(g->L);
+    (void)hipFree(g->X);
+    (void)hipFree(g->d_base);
+    (void)hipFree(g->vp.VH);
+    (void)hipFree(g->vp.VL);
+    (void)hipFree(g->vp.VX);
+    (void)hipFree(g->vp.tile_class);
+    delete g;
+}
+
+uint64_t prf_genome_positions(const prf_genome *g) { return g ? g->positions : 0; }
+
+static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out) {
+    if (!c || !out || n_contigs < 0 || (n_contigs > 0 && !contigs))
+        return fail(PRF_EINVAL, "prf_genome_load: bad arguments");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->dev));
+    if (kmax_hint < 1) kmax_hint = 1;
+    if (kmax_hint > 60000) return fail(PRF_EUNSUPPORTED, "prf_genome_load: kmax_hint %u > 60000", kmax_hint);
+    prf_genome *g = new (std::nothrow) prf_genome();
+    if (!g) return fail(PRF_ENOMEM, "prf_genome_load: out of host memory");
+    struct guard_t {
+        prf_genome *g;
+        ~guard_t() { if (g) prf_genome_free(g); }
+    } guard{g};
+    g->ctx = c;
+    g->kmax_hint = kmax_hint;
+    const u64 gap = (u64)kmax_hint + 64;
+    u64 cur = 0;
+    for (int i = 0; i < n_contigs; i++) {
+        if (contigs[i].len && !contigs[i].ascii) return fail(PRF_EINVAL, "prf_genome_load: contig %d has NULL data", i);
+        g->base.push_back(cur);
+        g->len.push_back(contigs[i].len);
+        g->positions += contigs[i].len;
+        cur = (cur + contigs[i].len + gap + PRF_TILE - 1) / PRF_TILE * PRF_TILE;
+    }
+    if (cur == 0) cur = PRF_TILE;
+    g->G = cur + PRF_TILE;  // one all-gap sentinel tile: every walk to the right ends inside the arrays
+    if (g->G >= (1ull << PRF_CAND_POS_BITS)) return fail(PRF_EUNSUPPORTED, "prf_genome_load: input too large");
+    g->nwords = g->G / 64;
+    g->padw = kmax_hint / 64 + 8;
+
+    uint8_t *asc = nullptr;
+    HIPCHK(hipMalloc((void **)&asc, g->G));
+    struct asc_guard_t {
+        uint8_t *p;
+        ~asc_guard_t() { (void)hipFree(p); }
+    } asc_guard{asc};
+    HIPCHK(prf_launch_fill_u64(c->stream, (u64 *)asc, g->G / 8, 0x4E4E4E4E4E4E4E4Eull));  // 'N' everywhere
+    for (int i = 0; i < n_contigs; i++)
+        if (contigs[i].len)
+            HIPCHK(hipMemcpyAsync(asc + g->base[i], contigs[i].ascii, contigs[i].len, hipMemcpyHostToDevice, c->stream));
+    const u64 tot = g->nwords + g->padw;
+    HIPCHK(hipMalloc((void **)&g->H, tot * 8));
+    HIPCHK(hipMalloc((void **)&g->L, tot * 8));
+    HIPCHK(hipMalloc((void **)&g->X, tot * 8));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0xFF, PRF_CNT_N * sizeof(u64), c->stream));
+    HIPCHK(prf_launch_pack_linear(c->stream, asc, g->nwords, g->H, g->L, g->X, c->d_counters + PRF_CNT_BADPOS));
+    HIPCHK(hipMemsetAsync(g->H + g->nwords, 0, g->padw * 8, c->stream));
+    HIPCHK(hipMemsetAsync(g->L + g->nwords, 0, g->padw * 8, c->stream));
+    HIPCHK(hipMemsetAsync(g->X + g->nwords, 0xFF, g->padw * 8, c->stream));
+    HIPCHK(hipMalloc((void **)&g->d_base, sizeof(u64) * (size_t)(n_contigs > 0 ? n_contigs : 1)));
+    if (n_contigs > 0)
+        HIPCHK(hipMemcpyAsync(g->d_base, g->base.data(), sizeof(u64) * (size_t)n_contigs, hipMemcpyHostToDevice, c->stream));
+    // bit-sliced copy for the vertical kernel (built from the ASCII while it is still resident)
+    {
+        int rc = prf_vertical_pack(c->stream, asc, g->G, &g->vp);
+        if (rc != hipSuccess) return fail(rc == (int)hipErrorOutOfMemory ? PRF_ENOMEM : PRF_EHIP, "vertical pack failed: %s",
+                                          hipGetErrorString((hipError_t)rc));
+    }
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const u64 bad = c->h_counters[PRF_CNT_BADPOS];
+    if (bad != ~0ull) {
+        size_t ci = std::upper_bound(g->base.begin(), g->base.end(), bad) - g->base.begin() - 1;
+        return fail(PRF_ESYMBOL,
+                    "unsupported symbol at contig %zu position %llu: only A,C,G,T,N (any case) can be packed; "
+                    "libprf refuses other symbols instead of guessing",
+                    ci, (unsigned long long)(bad - g->base[ci]));
+    }
+    guard.g = nullptr;
+    *out = g;
+    return PRF_OK;
+}
+
+int prf_genome_load(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out) {
+    try {
+        return genome_load_impl(c, contigs, n_contigs, kmax_hint, out);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_genome_load: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_genome_load: unexpected exception");
+    }
+}
+
+static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
+    if (want_cand > c->cand_cap) {
+        (void)hipFree(c->d_cand);
+        c->d_cand = nullptr;
+        c->cand_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_cand, want_cand * sizeof(u64)));
+        c->cand_cap = want_cand;
+    }
+    if (want_hits > c->hit_cap) {
+        (void)hipFree(c->d_hits);
+        c->d_hits = nullptr;
+        c->hit_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_hits, want_hits * sizeof(prf_hit_dev)));
+        c->hit_cap = want_hits;
+    }
+    return PRF_OK;
+}
+
+static int ensure_slabs(prf_ctx *c, u64 units, u32 cap) {
+    if (units > c->slab_units || cap > c->slab_cap) {
+        (void)hipFree(c->d_slabs);
+        (void)hipFree(c->d_slab_counts);
+        c->d_slabs = nullptr;
+        c->d_slab_counts = nullptr;
+        c->slab_units = 0;
+        c->slab_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_slabs, units * (u64)cap * sizeof(u64)));
+        HIPCHK(hipMalloc((void **)&c->d_slab_counts, units * sizeof(u32)));
+        c->slab_units = units;
+        c->slab_cap = cap;
+    }
+    return PRF_OK;
+}
+
+static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                     uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats) {
+    if (!c || !g) return fail(PRF_EINVAL, "prf_scan_genome: NULL context or genome");
+    if (g->ctx != c) return fail(PRF_EINVAL, "prf_scan_genome: genome belongs to another context");
+    if (out) { out->rows = nullptr; out->n = 0; }
+    // same conditions, same wording as the reference's ValueErrors (perfect_repeat_finder.py:23-30)
+    if (kmin < 1) return fail(PRF_EINVAL, "min_motif_size is set to %u. It must be at least 1.", kmin);
+    if (kmax < kmin) return fail(PRF_EINVAL, "max_motif_size is set to %u. It must be at least min_motif_size.", kmax);
+    if (min_repeats < 1) return fail(PRF_EINVAL, "min_repeats is set to %u. It must be at least 1.", min_repeats);
+    if (min_span < 1) return fail(PRF_EINVAL, "min_span is set to %u. It must be at least 1.", min_span);
+    if (min_repeats < 2)
+        return fail(PRF_EUNSUPPORTED, "min_repeats == 1 is outside the closed form implemented on the GPU (SURVEY 3.4)");
+    if (kmax > g->kmax_hint)
+        return fail(PRF_EUNSUPPORTED, "max_motif_size %u exceeds the kmax_hint %u this genome was packed with", kmax,
+                    g->kmax_hint);
+    if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
+    HIPCHK(hipSetDevice(c->dev));
+
+    prf_planes pl{g->H, g->L, g->X};
+    const prf_vspec *vs = (flags & PRF_SCAN_FORCE_GENERIC) ? nullptr : prf_vertical_find(kmin, kmax, min_repeats, min_span);
+    const u64 ntiles = g->G / PRF_TILE - 1;  // the sentinel tile is never scanned
+    u64 want_cand = std::max<u64>(c->cand_cap, g->positions / 8 + 65536);
+    u64 want_hits = std::max<u64>(c->hit_cap, g->positions / 32 + 65536);
+    u32 slab_cap = vs ? std::max<u32>(c->slab_cap, 256u) : 0;
+    float ms01 = 0, ms12 = 0;
+    u64 ncand = 0, nhits = 0;
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) return fail(PRF_EHIP, "prf_scan_genome: buffers still overflowing after 8 attempts");
+        int rc = ensure_buffers(c, want_cand, want_hits);
+        if (rc) return rc;
+        if (vs) {
+            rc = ensure_slabs(c, ntiles * vs->waves, slab_cap);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        if (vs) {
+            HIPCHK(prf_vertical_launch(c->stream, vs, g->vp, ntiles, c->d_slabs, c->d_slab_counts, c->slab_cap, c->d_cand,
+                                       c->cand_cap, c->d_counters));
+        } else {
+            HIPCHK(prf_launch_scan_generic(c->stream, pl, 0, g->nwords - PRF_TILE_WORDS, kmin, kmax, min_repeats, min_span,
+                                           c->d_cand, c->cand_cap, c->d_counters));
+        }
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base,
+                                 (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ncand = c->h_counters[PRF_CNT_CAND];
+        nhits = c->h_counters[PRF_CNT_HITS];
+        const u64 slab_ovf = c->h_counters[PRF_CNT_SLAB_OVF];  // largest per-slab demand seen, 0 if none overflowed
+        bool again = false;
+        if (ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
+        if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
+        if (slab_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(slab_ovf + slab_ovf / 4 + 64, 1u << 24); again = true; }
+        if (!again) break;
+    }
+    HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
+    if (stats) {
+        stats->phase1_ms = ms01;
+        stats->phase2_ms = ms12;
+        stats->scan_ms = (double)ms01 + (double)ms12;
+        stats->positions = g->positions;
+        stats->packed_bytes = (g->positions + 3) / 4;
+        stats->n_candidates = ncand;
+        stats->n_hits = nhits;
+        stats->n_launches = vs ? vs->launches + 1 : 2;
+        stats->path = vs ? 1 : 0;
+    }
+    if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
+    if (nhits == 0) return PRF_OK;
+    prf_hit *rows = (prf_hit *)malloc(nhits * sizeof(prf_hit));
+    if (!rows) return fail(PRF_ENOMEM, "prf_scan_genome: cannot allocate %llu rows", (unsigned long long)nhits);
+    static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
+    hipError_t e = hipMemcpy(rows, c->d_hits, nhits * sizeof(prf_hit), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(rows);
+        return fail(PRF_EHIP, "row copy failed: %s", hipGetErrorString(e));
+    }
+    std::sort(rows, rows + nhits, [](const prf_hit &a, const prf_hit &b) {
+        if (a.contig != b.contig) return a.contig < b.contig;
+        if (a.start != b.start) return a.start < b.start;
+        if (a.end != b.end) return a.end < b.end;
+        return a.k < b.k;
+    });
+    out->rows = rows;
+    out->n = nhits;
+    return PRF_OK;
+}
+
+int prf_scan_genome(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                    uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats) {
+    try {
+        return scan_impl(c, g, kmin, kmax, min_repeats, min_span, flags, out, stats);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_scan_genome: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_scan_genome: unexpected exception");
+    }
+}
+
+int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+             uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats) {
+    prf_genome *g = nullptr;
+    int rc = prf_genome_load(c, contigs, n_contigs, kmax, &g);
+    if (rc) return rc;
+    rc = prf_scan_genome(c, g, kmin, kmax, min_repeats, min_span, flags, out, stats);
+    prf_genome_free(g);
+    return rc;
+}
+
+void prf_free_hits(prf_hits *h) {
+    if (!h) return;
+    free(h->rows);
+    h->rows = nullptr;
+    h->n = 0;
+}
+
+int prf_measure_hbm_read(prf_ctx *c, uint64_t bytes, int iters, double *gbps) {
+    if (!c || !gbps || bytes < (1u << 20) || iters < 1) return fail(PRF_EINVAL, "prf_measure_hbm_read: bad arguments");
+    HIPCHK(hipSetDevice(c->dev));
+    bytes &= ~(uint64_t)15;
+    void *buf = nullptr;
+    u32 *sink = nullptr;
+    HIPCHK(hipMalloc(&buf, bytes));
+    hipError_t e = hipMalloc((void **)&sink, 64);
+    if (e != hipSuccess) { (void)hipFree(buf); return fail(PRF_ENOMEM, "hipMalloc failed"); }
+    (void)hipMemsetAsync(buf, 0x5A, bytes, c->stream);
+    float best = 1e30f;
+    for (int i = 0; i < iters + 1; i++) {  // first pass is a warm-up
+        (void)hipEventRecord(c->ev[0], c->stream);
+        (void)prf_launch_hbm_read(c->stream, buf, bytes, sink);
+        (void)hipEventRecord(c->ev[1], c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        if (i > 0 && ms < best) best = ms;
+    }
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    *gbps = (double)bytes / (best * 1e-3) / 1e9;
+    return PRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// pack.hip -- ASCII -> bit planes, on the device.
+//
+// Replaces the reference's input_sequence.upper() plus its two further whole-sequence copies
+// (reference perfect_repeat_finder.py:33, :46): the ASCII bytes are read once, case-folded in
+// registers and written as three 1-bit planes (H, L = base code, X = not-ACGT).
+#include "prf_device.h"
+#include "prf_host.h"
+
+// One thread packs one 64-position word: 64 bytes in (4 x 16-B loads), 3 x 8 bytes out.
+__global__ __launch_bounds__(256) void prf_pack_linear_kernel(const uint8_t *__restrict__ asc, u64 nwords,
+                                                              u64 *__restrict__ H, u64 *__restrict__ L,
+                                                              u64 *__restrict__ X, u64 *__restrict__ bad_pos) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(asc + w * 64);
+    u64 h = 0, l = 0, x = 0, bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = src[q];
+        const u32 d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u32 c = ((d[j] >> (8 * b)) & 0xFFu);
+                const u32 f = c & 0xDFu;  // ASCII case fold for letters (str.upper(), reference :33)
+                const u32 is_acgt = (f == 'A') | (f == 'C') | (f == 'G') | (f == 'T');
+                // only letters fold onto letters, so comparing the folded byte is exact for a-z/A-Z;
+                // bytes outside both letter ranges can never equal 'A','C','G','T','N' after the fold
+                // except 0x41..0x5A themselves.
+                const u32 is_n = (f == 'N');
+                const int bit = q * 16 + j * 4 + b;
+                h |= (u64)((f >> 2) & 1u & is_acgt) << bit;
+                l |= (u64)((f >> 1) & 1u & is_acgt) << bit;
+                x |= (u64)(is_acgt ^ 1u) << bit;
+                bad |= (u64)((is_acgt | is_n) ^ 1u) << bit;
+            }
+        }
+    }
+    H[w] = h;
+    L[w] = l;
+    X[w] = x;
+    if (bad) atomicMin(bad_pos, w * 64 + (u64)__builtin_ctzll(bad));
+}
+
+// fill value for guard gaps and padding: N
+__global__ void prf_fill_u64_kernel(u64 *__restrict__ p, u64 n, u64 v) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
+                                  u64 *bad_pos) {
+    const u32 bs = 256;
+    const u64 nb = (nwords + bs - 1) / bs;
+    hipLaunchKernelGGL(prf_pack_linear_kernel, dim3((u32)nb), dim3(bs), 0, s, asc, nwords, H, L, X, bad_pos);
+    return hipGetLastError();
+}
+
+hipError_t prf_launch_fill_u64(hipStream_t s, u64 *p, u64 n, u64 v) {
+    if (n == 0) return hipSuccess;
+    u64 nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(prf_fill_u64_kernel, dim3((u32)nb), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}

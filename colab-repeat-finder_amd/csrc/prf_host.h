@@ -1,0 +1,21 @@
+// prf_host.h -- launch wrappers shared between the kernel translation units and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "prf_device.h"
+
+// device counter block (u64 each)
+enum { PRF_CNT_CAND = 0, PRF_CNT_HITS = 1, PRF_CNT_BADPOS = 2, PRF_CNT_SLAB_OVF = 3, PRF_CNT_N = 8 };
+
+hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
+                                  u64 *bad_pos);
+hipError_t prf_launch_fill_u64(hipStream_t s, u64 *p, u64 n, u64 v);
+
+hipError_t prf_launch_scan_generic(hipStream_t s, const prf_planes &pl, u64 w_begin, u64 w_end, u32 kmin, u32 kmax,
+                                   u32 min_repeats, u32 min_span, u64 *cand, u64 cand_cap, u64 *counters);
+
+hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *cand, u64 cand_cap, u32 min_repeats,
+                             u32 min_span, const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap,
+                             u64 *counters);
+
+hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sink);

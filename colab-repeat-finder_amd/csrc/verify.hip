@@ -1,0 +1,118 @@
+// verify.hip -- phase 2: one lane per phase-1 candidate.
+//
+// What it replaces: PerfectRepeatTracker.output_interval_if_it_passes_filters()
+// (reference utils/perfect_repeat_tracker.py:71-101) and consists_of_perfect_repeats() (:108-142),
+// in the closed form of SURVEY 3.4 (valid for min_repeats >= 2):
+//     a maximal run [a,b) of matches at period k is a row (a, b+k, k)  iff
+//     b-a >= M(k) = max((min_repeats-1)*k, min_span-k)  and  seq[a:a+k] is a primitive word.
+// The "N in motif" drop (:83) is implied: with M(k) >= k every position of [a, b+k) is a
+// non-N base.  The keep-shorter de-duplication (:94-96) is dead in this regime (Fine-Wilf).
+#include "prf_device.h"
+#include "prf_host.h"
+
+// is seq[a : a+k] a whole number (>= 2) of copies of a shorter word?  A word of length k has a
+// proper divisor period iff it has period k/p for some prime p | k.
+__device__ bool prf_motif_is_repeat(const prf_planes &pl, u64 a, u32 k) {
+    u32 rest = k;
+    for (u32 p = 2; p <= rest; p++) {
+        if (rest % p) continue;
+        while (rest % p == 0) rest /= p;
+        const u32 d = k / p;      // candidate period
+        const u32 need = k - d;   // positions a .. a+need-1 must equal the ones d later
+        bool periodic = true;
+        for (u32 off = 0; off < need; off += 64) {
+            u64 mm = prf_mismatch64(pl, a + off, d);
+            const u32 left = need - off;
+            if (left < 64) mm &= (1ull << left) - 1ull;
+            if (mm) {
+                periodic = false;
+                break;
+            }
+        }
+        if (periodic) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void prf_verify_kernel(prf_planes pl, const u64 *__restrict__ cand, u64 cand_cap,
+                                                         u32 min_repeats, u32 min_span,
+                                                         const u64 *__restrict__ contig_base, u32 n_contigs,
+                                                         prf_hit_dev *__restrict__ hits, u64 hit_cap,
+                                                         u64 *__restrict__ counters) {
+    u64 n = counters[PRF_CNT_CAND];
+    if (n > cand_cap) n = cand_cap;  // overflow is reported to the host, which re-runs with a larger buffer
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 rec = cand[i];
+        const u64 p = rec & ((1ull << PRF_CAND_POS_BITS) - 1ull);
+        const u32 k = (u32)((rec >> PRF_CAND_K_SHIFT) & 0xFFFFu);
+        const u32 kind = (u32)(rec >> PRF_CAND_KIND_SHIFT);
+        u64 a = p;
+        u64 scan_from = p;
+        if (kind == PRF_KIND_GROUP) {
+            // [p, p+8) all match.  This group is the run's leader iff [p-8, p) is not all-match;
+            // otherwise an earlier aligned group reports the same run.
+            if (p >= 8) {
+                const u64 mm = prf_mismatch64(pl, p - 8, k) & 0xFFull;
+                if (mm == 0) continue;
+                a = p - (u64)__builtin_clzll(mm << 56);  // matches directly before p
+            }
+            scan_from = p + 8;
+        } else {
+            // exact start expected; a conservatively reported one may sit inside a run
+            if (p > 0 && (prf_mismatch64(pl, p - 1, k) & 1ull) == 0) continue;
+        }
+        // extend right to the first mismatch (the guard gap guarantees one)
+        u64 b = scan_from;
+        for (;;) {
+            const u64 mm = prf_mismatch64(pl, b, k);
+            if (mm) {
+                b += (u64)__builtin_ctzll(mm);
+                break;
+            }
+            b += 64;
+        }
+        const long long M = prf_min_matches(k, min_repeats, min_span);
+        if ((long long)(b - a) < M) continue;
+        if (prf_motif_is_repeat(pl, a, k)) continue;
+        // contig lookup: last base <= a
+        u32 lo = 0, hi = n_contigs;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (contig_base[mid] <= a) lo = mid; else hi = mid;
+        }
+        const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
+        if (slot < hit_cap) {
+            prf_hit_dev h;
+            h.start = a - contig_base[lo];
+            h.end = b + k - contig_base[lo];
+            h.k = k;
+            h.contig = lo;
+            hits[slot] = h;
+        }
+    }
+}
+
+hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *cand, u64 cand_cap, u32 min_repeats,
+                             u32 min_span, const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap,
+                             u64 *counters) {
+    hipLaunchKernelGGL(prf_verify_kernel, dim3(1024), dim3(256), 0, s, pl, cand, cand_cap, min_repeats, min_span,
+                       contig_base, n_contigs, hits, hit_cap, counters);
+    return hipGetLastError();
+}
+
+// streaming-read probe for the measured HBM roofline: 16 B per lane, grid-stride
+__global__ __launch_bounds__(256) void prf_hbm_read_kernel(const uint4 *__restrict__ p, u64 n16, u32 *__restrict__ sink) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 acc = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;  // keeps the loads alive, practically never stores
+}
+
+hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sink) {
+    hipLaunchKernelGGL(prf_hbm_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const uint4 *)p, bytes / 16, sink);
+    return hipGetLastError();
+}

@@ -1,0 +1,209 @@
+"""ctypes binding of libprf.so (C ABI in include/prf.h) -- the only door to the GPU.
+
+There is no CPU fallback behind this module: if the shared library is missing, or no gfx950
+device is usable, the calls raise.  PyTorch is not involved; the library owns its device
+memory and its HIP stream.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprf.so")
+
+PRF_OK = 0
+PRF_EINVAL = -1
+PRF_ENODEV = -2
+PRF_EHIP = -3
+PRF_ENOMEM = -4
+PRF_EUNSUPPORTED = -5
+PRF_ESYMBOL = -6
+
+SCAN_DEFAULT = 0
+SCAN_FORCE_GENERIC = 1
+SCAN_NO_FETCH = 2
+
+
+class PrfError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libprf error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class _Contig(ctypes.Structure):
+    _fields_ = [("ascii", ctypes.c_char_p), ("len", ctypes.c_uint64)]
+
+
+class _Hit(ctypes.Structure):
+    _fields_ = [("start", ctypes.c_uint64), ("end", ctypes.c_uint64), ("k", ctypes.c_uint32), ("contig", ctypes.c_uint32)]
+
+
+class _Hits(ctypes.Structure):
+    _fields_ = [("rows", ctypes.POINTER(_Hit)), ("n", ctypes.c_uint64)]
+
+
+class ScanStats(ctypes.Structure):
+    _fields_ = [("scan_ms", ctypes.c_double), ("phase1_ms", ctypes.c_double), ("phase2_ms", ctypes.c_double),
+                ("positions", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
+                ("n_hits", ctypes.c_uint64), ("n_launches", ctypes.c_uint32), ("path", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
+           "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
+           "prf_measure_hbm_read"]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libprf.so and declare the prototypes.  Raises if the library was not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C colab-repeat-finder_amd/csrc).  There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        lib.prf_abi_version.restype = ctypes.c_int
+        lib.prf_device_count.restype = ctypes.c_int
+        lib.prf_last_error.restype = ctypes.c_char_p
+        lib.prf_open.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        lib.prf_close.argtypes = [vp]
+        lib.prf_close.restype = None
+        lib.prf_genome_load.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(vp)]
+        lib.prf_genome_free.argtypes = [vp]
+        lib.prf_genome_free.restype = None
+        lib.prf_genome_positions.argtypes = [vp]
+        lib.prf_genome_positions.restype = ctypes.c_uint64
+        lib.prf_scan_genome.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.POINTER(_Hits), ctypes.POINTER(ScanStats)]
+        lib.prf_scan.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_Hits),
+                                 ctypes.POINTER(ScanStats)]
+        lib.prf_free_hits.argtypes = [ctypes.POINTER(_Hits)]
+        lib.prf_free_hits.restype = None
+        lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc != PRF_OK:
+        raise PrfError(rc, lib.prf_last_error().decode("utf-8", "replace"))
+
+
+def _contig_array(seqs):
+    arr = (_Contig * max(1, len(seqs)))()
+    for i, s in enumerate(seqs):
+        if not isinstance(s, (bytes, bytearray)):
+            raise TypeError("contigs must be bytes")
+        arr[i].ascii = bytes(s) if isinstance(s, bytearray) else s
+        arr[i].len = len(s)
+    return arr
+
+
+def _rows(hits):
+    n = hits.n
+    if n == 0:
+        return []
+    import numpy as np
+    buf = np.ctypeslib.as_array(ctypes.cast(hits.rows, ctypes.POINTER(ctypes.c_uint8)), shape=(n * ctypes.sizeof(_Hit),))
+    rec = buf.view(np.dtype([("start", "<u8"), ("end", "<u8"), ("k", "<u4"), ("contig", "<u4")])).copy()
+    return rec
+
+
+class Genome:
+    """Contigs packed and resident in HBM (prf_genome)."""
+
+    def __init__(self, ctx, handle, n_contigs):
+        self.ctx = ctx
+        self._h = handle
+        self.n_contigs = n_contigs
+
+    @property
+    def positions(self):
+        return self.ctx.lib.prf_genome_positions(self._h)
+
+    def scan(self, kmin, kmax, min_repeats, min_span, flags=SCAN_DEFAULT, fetch=True):
+        """Returns (rows, stats): rows is a numpy record array (start, end, k, contig) sorted by
+        (contig, start, end), or None when fetch=False."""
+        lib = self.ctx.lib
+        hits = _Hits()
+        stats = ScanStats()
+        f = flags | (0 if fetch else SCAN_NO_FETCH)
+        _check(lib, lib.prf_scan_genome(self.ctx._h, self._h, kmin, kmax, min_repeats, min_span, f,
+                                        ctypes.byref(hits), ctypes.byref(stats)))
+        if not fetch:
+            return None, stats
+        try:
+            return _rows(hits), stats
+        finally:
+            lib.prf_free_hits(ctypes.byref(hits))
+
+    def free(self):
+        if self._h is not None:
+            self.ctx.lib.prf_genome_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU, one HIP stream (prf_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.prf_open(device, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+
+    def load(self, seqs, kmax_hint):
+        arr = _contig_array(seqs)
+        g = ctypes.c_void_p()
+        _check(self.lib, self.lib.prf_genome_load(self._h, arr, len(seqs), kmax_hint, ctypes.byref(g)))
+        return Genome(self, g, len(seqs))
+
+    def scan(self, seqs, kmin, kmax, min_repeats, min_span, flags=SCAN_DEFAULT):
+        arr = _contig_array(seqs)
+        hits = _Hits()
+        stats = ScanStats()
+        _check(self.lib, self.lib.prf_scan(self._h, arr, len(seqs), kmin, kmax, min_repeats, min_span, flags,
+                                           ctypes.byref(hits), ctypes.byref(stats)))
+        try:
+            return _rows(hits), stats
+        finally:
+            self.lib.prf_free_hits(ctypes.byref(hits))
+
+    def measure_hbm_read(self, nbytes=1 << 30, iters=5):
+        out = ctypes.c_double(0)
+        _check(self.lib, self.lib.prf_measure_hbm_read(self._h, nbytes, iters, ctypes.byref(out)))
+        return out.value
+
+    def close(self):
+        if self._h is not None:
+            self.lib.prf_close(self._h)
+            self._h = None
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context for detect_repeats(); device from PRF_DEVICE / LOCAL_RANK / 0."""
+    if device is None:
+        device = int(os.environ.get("PRF_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's perfect_repeat_finder.py, running on an MI355X through libprf.
+
+API kept from the reference:
+  detect_repeats(input_sequence, filter_settings, verbose=False, show_progress_bar=False, debug=False)
+      -> [(start_0based, end, motif), ...] sorted by (start, end)   (reference perfect_repeat_finder.py:10-81)
+  find_repeats = detect_repeats   (the name BASELINE.json's north_star uses)
+  main()                           same flags, defaults, stdout lines and output files (reference :83-183)
+
+What differs underneath: the reference walks one PerfectRepeatTracker per motif size over the string,
+one character per call; here the sequence is packed into bit planes in HBM and scanned by HIP
+kernels.  The rows are bit-identical.  There is no CPU fallback: without libprf.so
+and a gfx950 device every scan raises.
+"""
+import argparse
+import os
+import re
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import libprf  # noqa: E402
+
+
+def _check_settings(fs):
+    """Same checks, same messages, same AttributeError-on-missing behaviour as reference :23-30."""
+    checks = (
+        ("min_motif_size", lambda v: v < 1, "It must be at least 1."),
+        ("max_motif_size", lambda v: v < fs.min_motif_size, "It must be at least min_motif_size."),
+        ("min_repeats", lambda v: v < 1, "It must be at least 1."),
+        ("min_span", lambda v: v < 1, "It must be at least 1."),
+    )
+    for name, bad, tail in checks:
+        value = getattr(fs, name)
+        if not value or bad(value):
+            raise ValueError(f"{name} is set to {value}. {tail}")
+
+
+def _to_ascii(seq):
+    try:
+        return seq.encode("ascii")
+    except UnicodeEncodeError as exc:
+        raise ValueError(f"input_sequence contains a non-ASCII character at offset {exc.start}; "
+                         "the packed GPU path accepts A,C,G,T,N in either case") from None
+
+
+def _gpu_rows(seq, fs, context=None):
+    """Closed-form rows of one sequence: list of (start, end, k), sorted by (start, end)."""
+    if fs.min_repeats < 2:
+        raise NotImplementedError(
+            "min_repeats == 1 is not supported on the GPU path: the reference's behaviour in that regime depends on "
+            "Python negative-index wrap-around (reference utils/perfect_repeat_tracker.py:87) and is not a closed form")
+    ctx = context or libprf.default_context()
+    try:
+        rows, _ = ctx.scan([_to_ascii(seq)], fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
+    except libprf.PrfError as exc:
+        if exc.code in (libprf.PRF_EINVAL, libprf.PRF_ESYMBOL):
+            raise ValueError(exc.message) from None
+        raise
+    return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in rows]
+
+
+def _interval_cutoff(seq, fs, end_position):
+    """Number of lock-step iterations the reference's position loop performs (reference :66-74) when
+    it may stop early: it stops at the first position past the interval end at which no motif size
+    is "in the middle of a repeat" (>= k consecutive matches so far, tracker :63-65).  Host-side
+    control logic over a handful of positions; the scan itself stays on the GPU."""
+    n = len(seq)
+    ks = range(fs.min_motif_size, fs.max_motif_size + 1)
+
+    def matches(j, k):
+        return seq[j] == seq[j + k] and seq[j] != "N"
+
+    # consecutive matches ending at the last position each tracker has processed at time end_position
+    run = {}
+    for k in ks:
+        last = min(end_position, n - k - 1)
+        c = 0
+        while last - c >= 0 and c < k and matches(last - c, k):
+            c += 1
+        run[k] = c
+    for t in range(end_position + 1, n):
+        busy = False
+        for k in ks:
+            if t <= n - k - 1:
+                run[k] = min(run[k] + 1, k) if matches(t, k) else 0
+            busy = busy or run[k] >= k
+        if not busy:
+            return t + 1
+    return n
+
+
+def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress_bar=False, debug=False, context=None):
+    """Detect perfect tandem repeats; see the module docstring.  `context` (a libprf.Context) is an
+    extension: by default a process-wide context on device PRF_DEVICE / LOCAL_RANK / 0 is used."""
+    _check_settings(filter_settings)
+    fs = filter_settings
+    if not hasattr(fs, "interval_start_0based") and not hasattr(fs, "interval_end"):
+        # no interval: N-trimming is a no-op on the rows (N never matches), SURVEY 3.4
+        rows = _gpu_rows(input_sequence, fs, context)
+        return [(s, e, input_sequence[s:s + k].upper()) for s, e, k in rows]
+
+    # interval mode, reference :35-46 and :61-81
+    seq = input_sequence.upper()
+    lo = getattr(fs, "interval_start_0based", 0)
+    hi = getattr(fs, "interval_end", len(seq))
+    total = len(seq)
+    while lo < hi and seq[lo] == "N":
+        lo += 1
+    while hi > lo and seq[hi - 1] == "N":
+        hi -= 1
+        total -= 1       # the reference shortens the whole sequence by the trimmed count (:44)
+    window = seq[lo:total]
+    rows = _gpu_rows(window, fs, context)
+    end_position = hi - lo
+    stop = _interval_cutoff(window, fs, end_position)
+    if hi == len(window) and stop < len(window) - fs.min_motif_size:
+        # reference :77-78: a tracker that has not reached the end of the sequence trips the assertion
+        raise AssertionError(f"{fs.min_motif_size}bp motif RepeatTracker did not reach end of the sequence")
+    if stop < len(window):
+        rows = [(s, e, k) for s, e, k in rows if e - k <= stop - 1]
+    return [(s + lo, e + lo, window[s:s + k]) for s, e, k in rows]
+
+
+find_repeats = detect_repeats
+
+
+# ----------------------------------------------------------------------------------------------
+# command line (reference :83-183)
+
+def _build_parser():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                description="Find perfect tandem repeats on an AMD MI355X.")
+    g = p.add_argument_group("Repeat Filters")
+    g.add_argument("-min", "--min-motif-size", type=int, default=1, help="Smallest motif size (bp).")
+    g.add_argument("-max", "--max-motif-size", type=int, default=50, help="Largest motif size (bp).")
+    g.add_argument("--min-repeats", type=int, default=3, help="Fewest copies of the motif a repeat must have.")
+    g.add_argument("--min-span", type=int, default=9, help="Fewest consecutive bases a repeat must cover.")
+    p.add_argument("-i", "--interval", help="Restrict the scan to chrom:start_0based-end.")
+    p.add_argument("-p", "--plot", help="Accepted for compatibility; plotting is not part of this build.")
+    p.add_argument("-o", "--output-prefix", help="Prefix of the output TSV (and BED, for FASTA input).")
+    p.add_argument("--verbose", action="store_true", help="Print verbose output.")
+    p.add_argument("--debug", action="store_true", help="Print debugging output.")
+    p.add_argument("--show-progress-bar", action="store_true", help="Accepted for compatibility (scans take milliseconds).")
+    p.add_argument("input_sequence", help="A nucleotide sequence, or the path of a FASTA file")
+    return p
+
+
+def _scan_fasta(args, parser):
+    from fasta import Fasta
+    if not args.output_prefix:
+        args.output_prefix = re.sub(".fa(sta)?(.gz)?", "", args.input_sequence)   # same unanchored pattern as reference :114
+    bed_path = f"{os.path.basename(args.output_prefix)}.bed"
+    entries = Fasta(args.input_sequence)
+    whole_contigs = True
+    if args.interval:
+        parts = re.split("[:-]", args.interval)
+        if len(parts) != 3:
+            parser.error("Invalid --interval format. Must be chrom:start_0based-end")
+        args.interval_chrom = parts[0]
+        args.interval_start_0based = int(parts[1])
+        args.interval_end = int(parts[2])
+        if args.interval_chrom not in entries:
+            parser.error(f"Chromosome {args.interval_chrom} not found in the input FASTA file")
+        entries = [entries[args.interval_chrom]]
+        whole_contigs = False
+    with open(bed_path, "wt") as bed:
+        for entry in entries:
+            seq = entry.seq
+            shown = len(seq)
+            settings = args
+            if whole_contigs:
+                # the reference crashes here without --interval (:139); scan the whole contig instead
+                settings = argparse.Namespace(min_motif_size=args.min_motif_size, max_motif_size=args.max_motif_size,
+                                              min_repeats=args.min_repeats, min_span=args.min_span)
+            else:
+                args.interval_end = min(args.interval_end, len(seq))
+                shown = args.interval_end - args.interval_start_0based
+            print(f"Processing {entry.name} ({shown:,d} bp)")
+            rows = detect_repeats(seq, settings, verbose=args.verbose, show_progress_bar=args.show_progress_bar,
+                                  debug=args.debug)
+            print(f"Found {len(rows):,d} repeats")
+            bed.writelines(f"{entry.name}\t{s}\t{e}\t{m}\n" for s, e, m in rows)
+    print(f"Wrote results to {bed_path}")
+
+
+def _scan_literal(args, parser):
+    if args.interval:
+        parser.error("The --interval option is only supported for FASTA files.")
+    if not args.output_prefix:
+        args.output_prefix = "repeats"
+    tsv_path = f"{args.output_prefix}.tsv"
+    rows = detect_repeats(args.input_sequence, args)
+    print(f"Found {len(rows):,d} repeats")
+    with open(tsv_path, "wt") as tsv:
+        tsv.write("start_0based\tend\tmotif\n")
+        tsv.writelines(f"{s}\t{e}\t{m}\n" for s, e, m in rows)
+    print(f"Wrote results to {tsv_path}")
+    if args.plot:
+        print("Warning: --plot is not implemented in this build. Skipping plot...")
+
+
+def main(argv=None):
+    parser = _build_parser()
+    args = parser.parse_args(argv)
+    if args.min_motif_size < 1:
+        parser.error(f"--min-motif-size is set to {args.min_motif_size}. It must be at least 1.")
+    if args.max_motif_size < args.min_motif_size:
+        parser.error(f"--max-motif-size is set to {args.max_motif_size}. It must be at least --min-motif-size.")
+    if args.min_repeats < 1:
+        parser.error(f"--min-repeats is set to {args.min_repeats}. It must be at least 1.")
+    if args.min_span < 1:
+        parser.error(f"--min-span is set to {args.min_span}. It must be at least 1.")
+    if os.path.isfile(args.input_sequence):
+        _scan_fasta(args, parser)
+    elif set(args.input_sequence.upper()) <= set("ACGTN"):
+        _scan_literal(args, parser)
+    else:
+        parser.error(f"Invalid input: {args.input_sequence}. This should be a FASTA file path or a string of nucleotides.")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/*
+ * prf.h -- C ABI of libprf, the MI355X (gfx950) perfect-tandem-repeat scanner.
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * broadinstitute/colab-repeat-finder: "for every motif size k in [min,max]
+ * compare seq[i] with seq[i+k] and report every maximal run that passes
+ * min_repeats / min_span and whose motif is primitive".
+ *
+ * The reference has no FFI of its own (it is pure Python); the seam this
+ * library sits behind is the Python call
+ *
+ *     detect_repeats(input_sequence, filter_settings, ...)      reference perfect_repeat_finder.py:10-81
+ *
+ * which drives one PerfectRepeatTracker per motif size
+ * (reference utils/perfect_repeat_tracker.py:3-142).  A maintainer of the
+ * reference binds these entry points with ctypes -- see INTEGRATION.md for the
+ * stub -- and replaces the body of detect_repeats() with one prf_scan() call.
+ *
+ * Conventions: plain C types only; every function returns PRF_OK (0) or a
+ * negative prf_status; nothing throws or exits across the boundary;
+ * prf_last_error() gives a thread-local message for the last failure.
+ * A prf_ctx is bound to one GPU and one HIP stream; calls on one ctx must be
+ * serialised by the caller (the reference is single-threaded, re-entrant and
+ * has no module globals -- neither has this library beyond the error string).
+ * There is NO CPU fallback: without a usable gfx950 device prf_open() fails.
+ */
+#ifndef PRF_H
+#define PRF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRF_ABI_VERSION 1
+
+typedef enum prf_status {
+    PRF_OK = 0,
+    PRF_EINVAL = -1,       /* bad argument (same conditions the reference raises ValueError for, :23-30)  */
+    PRF_ENODEV = -2,       /* no HIP device / wrong architecture                                          */
+    PRF_EHIP = -3,         /* a HIP runtime call failed (see prf_last_error)                              */
+    PRF_ENOMEM = -4,       /* host or device allocation failed                                            */
+    PRF_EUNSUPPORTED = -5, /* parameter regime outside the closed form (min_repeats < 2; kmax > hint)     */
+    PRF_ESYMBOL = -6       /* a byte other than ACGTN/acgtn: the packed fast path refuses it loudly        */
+} prf_status;
+
+typedef struct prf_ctx prf_ctx;       /* device, stream, scratch                           */
+typedef struct prf_genome prf_genome; /* contigs packed and resident in HBM                */
+
+/* One input sequence; caller-owned, read-only for the duration of the call.
+ * Replaces the Python str handed to detect_repeats() (reference :10, :33). */
+typedef struct prf_contig {
+    const uint8_t *ascii; /* raw bytes, any case; upper-casing (reference :33) is folded into the packer */
+    uint64_t len;
+} prf_contig;
+
+/* One output row = one (start_0based, end, motif) tuple of the reference (:81, :101);
+ * the motif text is seq.upper()[start:start+k], materialised by the caller. */
+typedef struct prf_hit {
+    uint64_t start;  /* 0-based, contig-local                                  */
+    uint64_t end;    /* exclusive                                              */
+    uint32_t k;      /* motif size                                             */
+    uint32_t contig; /* index into the contigs array                           */
+} prf_hit;
+
+typedef struct prf_hits {
+    prf_hit *rows; /* library-owned; sorted by (contig, start, end) like reference :81 */
+    uint64_t n;
+} prf_hits;
+
+/* Per-call counters for bench.py / --stats (none of this exists in the reference). */
+typedef struct prf_scan_stats {
+    double scan_ms;         /* HIP-event time on the ctx stream: first scan kernel start -> hit count ready */
+    double phase1_ms;       /* candidate-finding kernel(s)                                               */
+    double phase2_ms;       /* candidate verification / extension / filters / compaction                 */
+    uint64_t positions;     /* sum of contig lengths scanned                                             */
+    uint64_t packed_bytes;  /* ceil(positions/4): the algorithmic input bytes                            */
+    uint64_t n_candidates;  /* phase-1 candidates                                                        */
+    uint64_t n_hits;        /* rows                                                                      */
+    uint32_t n_launches;    /* kernel launches in the timed region                                       */
+    uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel                        */
+} prf_scan_stats;
+
+/* prf_scan flags */
+#define PRF_SCAN_DEFAULT 0u
+#define PRF_SCAN_FORCE_GENERIC 1u /* use the generic (any k, any thresholds) kernel even if a tuned one exists */
+#define PRF_SCAN_NO_FETCH 2u      /* leave rows on the device (out may be NULL); for timing loops               */
+
+int prf_abi_version(void);
+int prf_device_count(void);
+const char *prf_last_error(void);
+
+/* Bind a context to HIP device `device_id` (must be gfx950). */
+int prf_open(int device_id, prf_ctx **out);
+void prf_close(prf_ctx *ctx);
+
+/* Upload + pack contigs: ASCII -> 2-bit planes (+ a not-ACGT plane) resident in HBM.
+ * Replaces input_sequence.upper() and the three transient copies of reference :33-46.
+ * kmax_hint: largest motif size later scans will use (sizes the inter-contig guard gap). */
+int prf_genome_load(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out);
+void prf_genome_free(prf_genome *g);
+uint64_t prf_genome_positions(const prf_genome *g);
+
+/* The hot path on a resident genome: every k in [kmin,kmax], rows as reference :81.
+ * Requires min_repeats >= 2 (PRF_EUNSUPPORTED otherwise: reference behaviour for
+ * min_repeats == 1 depends on Python negative-index wrap-around). */
+int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                    uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
+
+/* One-shot convenience = prf_genome_load + prf_scan_genome + prf_genome_free.
+ * This is the call that replaces the body of reference detect_repeats() (:33-81). */
+int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax,
+             uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
+
+void prf_free_hits(prf_hits *hits);
+
+/* Roofline probe: streaming 16-byte-per-lane read of `bytes` bytes, best of `iters`; GB/s (1e9). */
+int prf_measure_hbm_read(prf_ctx *ctx, uint64_t bytes, int iters, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRF_H */
