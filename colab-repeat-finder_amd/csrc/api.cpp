@@ -55,6 +55,7 @@ struct prf_ctx {
     u64 *d_slabs = nullptr;
     u64 slab_units = 0;            // number of (tile, wave) slabs allocated
     u32 slab_cap = 0;              // records per slab
+    u64 last_nhits = 0;            // rows of the last scan still resident in d_hits
 };
 
 struct prf_genome {
@@ -317,6 +318,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     }
     HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
+    c->last_nhits = nhits;
     if (stats) {
         stats->phase1_ms = ms01;
         stats->phase2_ms = ms12;
@@ -368,6 +370,18 @@ int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin
     rc = prf_scan_genome(c, g, kmin, kmax, min_repeats, min_span, flags, out, stats);
     prf_genome_free(g);
     return rc;
+}
+
+int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, uint64_t *n_rows) {
+    if (!c || !n_rows || (capacity_rows && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
+    HIPCHK(hipSetDevice(c->dev));
+    *n_rows = c->last_nhits;
+    const u64 n = std::min<u64>(c->last_nhits, capacity_rows);
+    if (n) {
+        HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return PRF_OK;
 }
 
 void prf_free_hits(prf_hits *h) {

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
-import libprf  # noqa: E402
+import prf_native  # noqa: E402
 
 
 def _check_settings(fs):
@@ -52,11 +52,11 @@ def _gpu_rows(seq, fs, context=None):
         raise NotImplementedError(
             "min_repeats == 1 is not supported on the GPU path: the reference's behaviour in that regime depends on "
             "Python negative-index wrap-around (reference utils/perfect_repeat_tracker.py:87) and is not a closed form")
-    ctx = context or libprf.default_context()
+    ctx = context or prf_native.default_context()
     try:
         rows, _ = ctx.scan([_to_ascii(seq)], fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
-    except libprf.PrfError as exc:
-        if exc.code in (libprf.PRF_EINVAL, libprf.PRF_ESYMBOL):
+    except prf_native.PrfError as exc:
+        if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
             raise ValueError(exc.message) from None
         raise
     return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in rows]
@@ -93,7 +93,7 @@ def _interval_cutoff(seq, fs, end_position):
 
 
 def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress_bar=False, debug=False, context=None):
-    """Detect perfect tandem repeats; see the module docstring.  `context` (a libprf.Context) is an
+    """Detect perfect tandem repeats; see the module docstring.  `context` (a prf_native.Context) is an
     extension: by default a process-wide context on device PRF_DEVICE / LOCAL_RANK / 0 is used."""
     _check_settings(filter_settings)
     fs = filter_settings

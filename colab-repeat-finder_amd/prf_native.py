@@ -54,7 +54,7 @@ class ScanStats(ctypes.Structure):
 
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
-           "prf_measure_hbm_read"]
+           "prf_measure_hbm_read", "prf_last_hits_to_device"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -90,6 +90,7 @@ def load_library():
         lib.prf_free_hits.argtypes = [ctypes.POINTER(_Hits)]
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
         return lib
 
@@ -185,6 +186,12 @@ class Context:
             return _rows(hits), stats
         finally:
             self.lib.prf_free_hits(ctypes.byref(hits))
+
+    def last_hits_to_device(self, dst_ptr, capacity_rows):
+        """D2D copy of the last scan's rows into caller-owned device memory; returns the row count."""
+        n = ctypes.c_uint64(0)
+        _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows, ctypes.byref(n)))
+        return n.value
 
     def measure_hbm_read(self, nbytes=1 << 30, iters=5):
         out = ctypes.c_double(0)

@@ -115,6 +115,11 @@ int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t km
 
 void prf_free_hits(prf_hits *hits);
 
+/* Device-side hand-off of the rows of the LAST prf_scan_genome() on this context (unsorted, 24-byte
+ * prf_hit records): copied device-to-device into caller-owned device memory (e.g. a torch tensor that
+ * an RCCL gather then ships to rank 0).  *n_rows receives the row count; at most capacity_rows are copied. */
+int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, uint64_t *n_rows);
+
 /* Roofline probe: streaming 16-byte-per-lane read of `bytes` bytes, best of `iters`; GB/s (1e9). */
 int prf_measure_hbm_read(prf_ctx *ctx, uint64_t bytes, int iters, double *gbps);
 

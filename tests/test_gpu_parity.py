@@ -1,0 +1,135 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the golden fixtures and the oracle.
+Integer / index work: the bar is bit-exact rows."""
+import argparse
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import expected, outcome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import prf_native
+    c = prf_native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def detect(ctx):
+    import perfect_repeat_finder as prf
+
+    def run(seq, fs):
+        return prf.detect_repeats(seq, fs, context=ctx)
+    return run
+
+
+def rows_as_tuples(rows):
+    return [(int(r["contig"]), int(r["start"]), int(r["end"]), int(r["k"])) for r in rows]
+
+
+def oracle_rows(seq_bytes, kmin, kmax, r, span):
+    from oracle import prf_oracle
+    return [(s, e, k) for s, e, _ml, k in prf_oracle.detect_rows(seq_bytes, kmin, kmax, r, span)]
+
+
+def test_reference_unit_vectors(detect, golden_unit):
+    for case in golden_unit:
+        assert outcome(detect, case["seq"], case["settings"]) == ("ok", case["rows"]), case["tag"]
+
+
+def test_fuzz_small(detect, golden_fuzz):
+    n = 0
+    for case in golden_fuzz:
+        if case["settings"]["min_repeats"] < 2:
+            continue
+        n += 1
+        assert outcome(detect, case["seq"], case["settings"]) == expected(case), case
+    assert n > 3000
+
+
+def test_adversarial(detect, golden_adversarial):
+    for case in golden_adversarial:
+        assert outcome(detect, case["seq"], case["settings"]) == expected(case), case["tag"]
+
+
+def test_chr22_clusters_as_one_multi_contig_genome(ctx, golden_clusters):
+    """8000 real-genome known-answer clusters, loaded as 8000 contigs of one resident genome."""
+    seqs = [seq.encode() for _pos, seq, _want in golden_clusters]
+    rows, stats = ctx.scan(seqs, 1, 6, 3, 9)
+    got = {}
+    for c, s, e, k in rows_as_tuples(rows):
+        got.setdefault(c, []).append((s, e, golden_clusters[c][1][s:s + k]))
+    for i, (_pos, _seq, want) in enumerate(golden_clusters):
+        assert got.get(i, []) == want, i
+    assert stats.n_hits == sum(len(w) for _p, _s, w in golden_clusters)
+
+
+def test_synthetic_golden(detect):
+    from oracle import prf_oracle
+    files = sorted(glob.glob(os.path.join(GOLDEN, "synth_*.json")))
+    assert len(files) >= 5
+    for path in files:
+        with open(path) as f:
+            g = json.load(f)
+        seq = prf_oracle.synth(g["n"], g["seed"]).decode()
+        assert outcome(detect, seq, g["settings"]) == ("ok", g["rows"]), path
+
+
+def test_generic_kernel_param_sweep_vs_oracle(ctx):
+    """Seeded inputs at sizes the oracle finishes in seconds, many parameter sets, forced generic kernel."""
+    import prf_native
+    import synth
+    seq = synth.chr_standin(length=400_000, seed=11, n_head=30_000, n_tail=2_000, repeats_per_mbp=4000).tobytes()
+    g = ctx.load([seq], 130)
+    try:
+        for kmin, kmax, r, span in [(1, 50, 3, 9), (2, 6, 3, 9), (1, 6, 3, 9), (1, 100, 3, 9), (5, 64, 2, 1), (1, 130, 4, 30),
+                                    (63, 65, 2, 5), (1, 20, 3, 12), (1, 10, 3, 7), (3, 3, 2, 100)]:
+            rows, stats = g.scan(kmin, kmax, r, span, flags=prf_native.SCAN_FORCE_GENERIC)
+            assert stats.path == 0
+            got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+            assert got == oracle_rows(seq, kmin, kmax, r, span), (kmin, kmax, r, span)
+    finally:
+        g.free()
+
+
+def test_errors_cross_the_boundary_cleanly(ctx):
+    import prf_native
+    with pytest.raises(prf_native.PrfError) as info:
+        ctx.scan([b"ACGTRYACGT"], 1, 5, 3, 9)
+    assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
+    with pytest.raises(prf_native.PrfError) as info:
+        ctx.scan([b"ACGT"], 1, 5, 1, 9)
+    assert info.value.code == prf_native.PRF_EUNSUPPORTED
+    with pytest.raises(prf_native.PrfError) as info:
+        ctx.scan([b"ACGT"], 0, 5, 3, 9)
+    assert info.value.code == prf_native.PRF_EINVAL
+    rows, _ = ctx.scan([], 1, 5, 3, 9)
+    assert len(rows) == 0
+    rows, _ = ctx.scan([b"", b"ACACACACACAC", b""], 1, 5, 3, 9)
+    assert rows_as_tuples(rows) == [(1, 0, 12, 2)]
+
+
+def test_full_size_chr22_standin_vs_oracle(ctx):
+    """BASELINE config C2 at full size (50 818 468 bp, motif 1-50): rows bit-exact against the oracle."""
+    import synth
+    seq = synth.chr_standin().tobytes()
+    rows, stats = ctx.scan([seq], 1, 50, 3, 9)
+    got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+    # size-independent properties first (cheap, and they localise a failure)
+    starts = np.array([g[0] for g in got])
+    ends = np.array([g[1] for g in got])
+    ks = np.array([g[2] for g in got])
+    assert len(got) > 50_000
+    assert np.all((starts[1:] > starts[:-1]) | ((starts[1:] == starts[:-1]) & (ends[1:] > ends[:-1])))  # strictly sorted
+    assert np.all(ends - starts >= np.maximum(3 * ks, 9))
+    assert starts.min() >= 10_510_000 and ends.max() <= len(seq) - 10_000
+    want = oracle_rows(seq, 1, 50, 3, 9)
+    assert got == want
