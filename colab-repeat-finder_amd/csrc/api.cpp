@@ -136,6 +136,7 @@ void prf_genome_free(prf_genome *g) {
     (void)hipFree(g->vp.VL);
     (void)hipFree(g->vp.VX);
     (void)hipFree(g->vp.tile_class);
+    (void)hipFree(g->vp.tile_list);
     delete g;
 }
 
@@ -295,15 +296,19 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
         HIPCHK(hipEventRecord(c->ev[0], c->stream));
         if (vs) {
-            HIPCHK(prf_vertical_launch(c->stream, vs, g->vp, ntiles, c->d_slabs, c->d_slab_counts, c->slab_cap, c->d_cand,
-                                       c->cand_cap, c->d_counters));
+            HIPCHK(prf_vertical_launch(c->stream, vs, g->vp, c->d_slabs, c->d_slab_counts, c->slab_cap, c->d_counters));
         } else {
             HIPCHK(prf_launch_scan_generic(c->stream, pl, 0, g->nwords - PRF_TILE_WORDS, kmin, kmax, min_repeats, min_span,
                                            c->d_cand, c->cand_cap, c->d_counters));
         }
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
-        HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base,
-                                 (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
+        if (vs)
+            HIPCHK(prf_launch_verify_slabs(c->stream, pl, c->d_slabs, c->d_slab_counts, c->slab_cap, g->vp.tile_list,
+                                           g->vp.n_clean + g->vp.n_mixed, vs->waves, min_repeats, min_span, g->d_base,
+                                           (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
+        else
+            HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base,
+                                     (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
         HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -311,7 +316,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         nhits = c->h_counters[PRF_CNT_HITS];
         const u64 slab_ovf = c->h_counters[PRF_CNT_SLAB_OVF];  // largest per-slab demand seen, 0 if none overflowed
         bool again = false;
-        if (ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
+        if (!vs && ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
         if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
         if (slab_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(slab_ovf + slab_ovf / 4 + 64, 1u << 24); again = true; }
         if (!again) break;
@@ -327,7 +332,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         stats->packed_bytes = (g->positions + 3) / 4;
         stats->n_candidates = ncand;
         stats->n_hits = nhits;
-        stats->n_launches = vs ? vs->launches + 1 : 2;
+        stats->n_launches = vs ? (g->vp.n_clean ? 1 : 0) + (g->vp.n_mixed ? 1 : 0) + 1 : 2;
         stats->path = vs ? 1 : 0;
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;

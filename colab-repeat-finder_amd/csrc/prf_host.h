@@ -18,4 +18,8 @@ hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *can
                              u32 min_span, const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap,
                              u64 *counters);
 
+hipError_t prf_launch_verify_slabs(hipStream_t s, const prf_planes &pl, const u64 *slabs, const u32 *slab_counts,
+                                   u32 slab_cap, const u32 *tile_list, u32 n_tiles, u32 nw, u32 min_repeats, u32 min_span,
+                                   const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap, u64 *counters);
+
 hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sink);

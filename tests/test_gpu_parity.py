@@ -100,6 +100,48 @@ def test_generic_kernel_param_sweep_vs_oracle(ctx):
         g.free()
 
 
+VSPECS = [(1, 50, 3, 9), (1, 100, 3, 9), (2, 6, 3, 9), (1, 6, 3, 9), (1, 7, 3, 6), (2, 10, 3, 6), (1, 10, 3, 6),
+          (1, 20, 3, 12), (1, 10, 3, 7), (5, 64, 2, 1), (1, 30, 2, 20)]
+
+
+def test_bit_sliced_kernel_every_compiled_spec_vs_oracle_and_generic(ctx):
+    """The bit-sliced (vertical) kernel, for every parameter set it is compiled for, against the oracle and
+    against the generic kernel; the input has N blocks that start and end inside tiles, so both the clean
+    and the not-ACGT tile variants run, and planted repeats that cross stream and tile edges."""
+    import prf_native
+    import synth
+    seq = bytearray(synth.chr_standin(length=700_000, seed=5, n_head=70_000, n_tail=3_000, repeats_per_mbp=5000).tobytes())
+    seq[200_000:200_400] = b"N" * 400                       # N block inside a tile
+    seq[65_536 * 4 - 40:65_536 * 4 + 60] = b"ACG" * 33 + b"A"  # run across a tile edge
+    seq[65_536 * 5 - 9:65_536 * 5 + 9] = b"T" * 18          # homopolymer across a tile edge
+    seq[300_000:300_000 + 2048 * 3] = (b"CAGT" * 2048)[:2048 * 3]  # run longer than several streams
+    seq[400_000] = ord("N")                                  # single N
+    seq = bytes(seq)
+    g = ctx.load([seq], 130)
+    try:
+        for kmin, kmax, r, span in VSPECS:
+            rows, stats = g.scan(kmin, kmax, r, span)
+            assert stats.path == 1, (kmin, kmax, r, span)
+            got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+            assert got == oracle_rows(seq, kmin, kmax, r, span), (kmin, kmax, r, span)
+            rows2, stats2 = g.scan(kmin, kmax, r, span, flags=prf_native.SCAN_FORCE_GENERIC)
+            assert stats2.path == 0
+            assert rows_as_tuples(rows2) == rows_as_tuples(rows)
+    finally:
+        g.free()
+
+
+def test_bit_sliced_kernel_slab_overflow_and_long_runs(ctx):
+    """An all-A contig is one run for every k: every stream start is a (spurious) candidate, the candidate
+    slabs overflow and the scan must grow them and still return the exact rows."""
+    seq = b"A" * 300_000 + b"C" + b"GT" * 40_000
+    rows, stats = ctx.scan([seq], 1, 50, 3, 9)
+    assert stats.path == 1
+    got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+    assert got == [(0, 300_000, 1), (300_001, 380_001, 2)]
+    assert stats.n_candidates > 100_000
+
+
 def test_errors_cross_the_boundary_cleanly(ctx):
     import prf_native
     with pytest.raises(prf_native.PrfError) as info:
