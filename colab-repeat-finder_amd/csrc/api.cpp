@@ -23,6 +23,8 @@
 
 static thread_local std::string g_err;
 
+static const u64 PRF_FRONT_PAD = 8;  // readable words in front of every linear plane (X = all ones there)
+
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -47,15 +49,22 @@ struct prf_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 *d_counters = nullptr;
     u64 *h_counters = nullptr;  // pinned
+    // generic path scratch
     u64 *d_cand = nullptr;
     u64 cand_cap = 0;
-    prf_hit_dev *d_hits = nullptr;
+    prf_hit_dev *d_hits = nullptr;  // flat rows: generic path output, or the compacted rows of the fused path
     u64 hit_cap = 0;
-    u32 *d_slab_counts = nullptr;  // vertical path: per (tile, wave) candidate counts
-    u64 *d_slabs = nullptr;
-    u64 slab_units = 0;            // number of (tile, wave) slabs allocated
-    u32 slab_cap = 0;              // records per slab
-    u64 last_nhits = 0;            // rows of the last scan still resident in d_hits
+    // fused (bit-sliced) path scratch: one row slab per tile
+    prf_hit_dev *d_hit_slabs = nullptr;
+    u32 *d_hit_counts = nullptr;
+    u64 *d_offsets = nullptr;
+    u64 slab_tiles = 0;
+    u32 slab_cap = 0;
+    u64 slab_serial = 0;  // genome whose tile list the slab counts currently reflect
+    // where the rows of the last scan are
+    u64 last_nhits = 0;
+    bool last_in_slabs = false;  // true: still in per-tile slabs (fused path), compact on demand
+    u64 last_ntiles = 0;
 };
 
 struct prf_genome {
@@ -66,7 +75,8 @@ struct prf_genome {
     u64 nwords = 0;      // G / 64
     u64 padw = 0;        // readable words past nwords in every linear plane
     u32 kmax_hint = 0;
-    u64 *H = nullptr, *L = nullptr, *X = nullptr;
+    u64 serial = 0;      // unique per loaded genome
+    u64 *H = nullptr, *L = nullptr, *X = nullptr;  // point PRF_FRONT_PAD words into their allocations
     u64 *d_base = nullptr;
     prf_vplanes vp;      // bit-sliced copy for scan_vertical
 };
@@ -117,8 +127,9 @@ void prf_close(prf_ctx *c) {
     (void)hipHostFree(c->h_counters);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
-    (void)hipFree(c->d_slab_counts);
-    (void)hipFree(c->d_slabs);
+    (void)hipFree(c->d_hit_slabs);
+    (void)hipFree(c->d_hit_counts);
+    (void)hipFree(c->d_offsets);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -128,9 +139,9 @@ void prf_close(prf_ctx *c) {
 void prf_genome_free(prf_genome *g) {
     if (!g) return;
     if (g->ctx) (void)hipSetDevice(g->ctx->dev);
-    (void)hipFree(g->H);
-    (void)hipFree(g->L);
-    (void)hipFree(g->X);
+    if (g->H) (void)hipFree(g->H - PRF_FRONT_PAD);
+    if (g->L) (void)hipFree(g->L - PRF_FRONT_PAD);
+    if (g->X) (void)hipFree(g->X - PRF_FRONT_PAD);
     (void)hipFree(g->d_base);
     (void)hipFree(g->vp.VH);
     (void)hipFree(g->vp.VL);
@@ -155,7 +166,9 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
         prf_genome *g;
         ~guard_t() { if (g) prf_genome_free(g); }
     } guard{g};
+    static u64 next_serial = 1;
     g->ctx = c;
+    g->serial = __atomic_fetch_add(&next_serial, 1, __ATOMIC_RELAXED);
     g->kmax_hint = kmax_hint;
     const u64 gap = (u64)kmax_hint + 64;
     u64 cur = 0;
@@ -182,10 +195,19 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     for (int i = 0; i < n_contigs; i++)
         if (contigs[i].len)
             HIPCHK(hipMemcpyAsync(asc + g->base[i], contigs[i].ascii, contigs[i].len, hipMemcpyHostToDevice, c->stream));
-    const u64 tot = g->nwords + g->padw;
-    HIPCHK(hipMalloc((void **)&g->H, tot * 8));
-    HIPCHK(hipMalloc((void **)&g->L, tot * 8));
-    HIPCHK(hipMalloc((void **)&g->X, tot * 8));
+    const u64 tot = PRF_FRONT_PAD + g->nwords + g->padw;
+    {
+        u64 *p = nullptr;
+        HIPCHK(hipMalloc((void **)&p, tot * 8));
+        g->H = p + PRF_FRONT_PAD;
+        HIPCHK(hipMalloc((void **)&p, tot * 8));
+        g->L = p + PRF_FRONT_PAD;
+        HIPCHK(hipMalloc((void **)&p, tot * 8));
+        g->X = p + PRF_FRONT_PAD;
+    }
+    HIPCHK(hipMemsetAsync(g->H - PRF_FRONT_PAD, 0, PRF_FRONT_PAD * 8, c->stream));
+    HIPCHK(hipMemsetAsync(g->L - PRF_FRONT_PAD, 0, PRF_FRONT_PAD * 8, c->stream));
+    HIPCHK(hipMemsetAsync(g->X - PRF_FRONT_PAD, 0xFF, PRF_FRONT_PAD * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters, 0xFF, PRF_CNT_N * sizeof(u64), c->stream));
     HIPCHK(prf_launch_pack_linear(c->stream, asc, g->nwords, g->H, g->L, g->X, c->d_counters + PRF_CNT_BADPOS));
     HIPCHK(hipMemsetAsync(g->H + g->nwords, 0, g->padw * 8, c->stream));
@@ -243,19 +265,42 @@ static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
     return PRF_OK;
 }
 
-static int ensure_slabs(prf_ctx *c, u64 units, u32 cap) {
-    if (units > c->slab_units || cap > c->slab_cap) {
-        (void)hipFree(c->d_slabs);
-        (void)hipFree(c->d_slab_counts);
-        c->d_slabs = nullptr;
-        c->d_slab_counts = nullptr;
-        c->slab_units = 0;
-        c->slab_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->d_slabs, units * (u64)cap * sizeof(u64)));
-        HIPCHK(hipMalloc((void **)&c->d_slab_counts, units * sizeof(u32)));
-        c->slab_units = units;
-        c->slab_cap = cap;
+static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap, u64 serial) {
+    if (ntiles <= c->slab_tiles && cap <= c->slab_cap && serial != c->slab_serial) {
+        // another genome: tiles that are never launched (nothing but N) must read as empty
+        HIPCHK(hipMemsetAsync(c->d_hit_counts, 0, c->slab_tiles * sizeof(u32), c->stream));
+        c->slab_serial = serial;
     }
+    if (ntiles > c->slab_tiles || cap > c->slab_cap) {
+        (void)hipFree(c->d_hit_slabs);
+        (void)hipFree(c->d_hit_counts);
+        (void)hipFree(c->d_offsets);
+        c->d_hit_slabs = nullptr;
+        c->d_hit_counts = nullptr;
+        c->d_offsets = nullptr;
+        c->slab_tiles = 0;
+        c->slab_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_hit_slabs, ntiles * (u64)cap * sizeof(prf_hit_dev)));
+        HIPCHK(hipMalloc((void **)&c->d_hit_counts, ntiles * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->d_offsets, (ntiles + 1) * sizeof(u64)));
+        // tiles that are never launched (nothing but N) must read as empty
+        HIPCHK(hipMemsetAsync(c->d_hit_counts, 0, ntiles * sizeof(u32), c->stream));
+        c->slab_tiles = ntiles;
+        c->slab_cap = cap;
+        c->slab_serial = serial;
+    }
+    return PRF_OK;
+}
+
+// fused path: rows of the last scan, per-tile slabs -> c->d_hits (compact, tile order)
+static int compact_last(prf_ctx *c) {
+    if (!c->last_in_slabs) return PRF_OK;
+    int rc = ensure_buffers(c, c->cand_cap, std::max<u64>(c->hit_cap, c->last_nhits + 1));
+    if (rc) return rc;
+    HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, c->last_ntiles, c->d_offsets,
+                                   c->d_hits));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->last_in_slabs = false;
     return PRF_OK;
 }
 
@@ -278,51 +323,80 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     HIPCHK(hipSetDevice(c->dev));
 
     prf_planes pl{g->H, g->L, g->X};
-    const prf_vspec *vs = (flags & PRF_SCAN_FORCE_GENERIC) ? nullptr : prf_vertical_find(kmin, kmax, min_repeats, min_span);
+    prf_vscan_args va;
+    bool vs = !(flags & PRF_SCAN_FORCE_GENERIC) && prf_vertical_plan(kmin, kmax, min_repeats, min_span, &va.plan);
     const u64 ntiles = g->G / PRF_TILE - 1;  // the sentinel tile is never scanned
     u64 want_cand = std::max<u64>(c->cand_cap, g->positions / 8 + 65536);
     u64 want_hits = std::max<u64>(c->hit_cap, g->positions / 32 + 65536);
-    u32 slab_cap = vs ? std::max<u32>(c->slab_cap, 256u) : 0;
+    u32 slab_cap = std::max<u32>(c->slab_cap, 512u);
     float ms01 = 0, ms12 = 0;
     u64 ncand = 0, nhits = 0;
+    u32 launches = 0;
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) return fail(PRF_EHIP, "prf_scan_genome: buffers still overflowing after 8 attempts");
-        int rc = ensure_buffers(c, want_cand, want_hits);
-        if (rc) return rc;
+        bool again = false;
         if (vs) {
-            rc = ensure_slabs(c, ntiles * vs->waves, slab_cap);
+            // ---- fused bit-sliced kernel: scan + verify + rows in one launch ----
+            int rc = ensure_slabs(c, ntiles, slab_cap, g->serial);
             if (rc) return rc;
-        }
-        HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
-        HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        if (vs) {
-            HIPCHK(prf_vertical_launch(c->stream, vs, g->vp, c->d_slabs, c->d_slab_counts, c->slab_cap, c->d_counters));
+            prf_vscan_args &a = va;
+            a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
+            a.H = g->H; a.L = g->L; a.X = g->X;
+            a.tile_list = g->vp.tile_list;
+            a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
+            a.hit_slabs = c->d_hit_slabs; a.hit_counts = c->d_hit_counts; a.hit_cap = c->slab_cap;
+            a.min_repeats = min_repeats; a.min_span = min_span;
+            a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
+            a.counters = c->d_counters;
+            HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+            HIPCHK(hipEventRecord(c->ev[0], c->stream));
+            HIPCHK(prf_vertical_launch(c->stream, a));
+            HIPCHK(hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
+            ms12 = 0;
+            launches = 1;
+            ncand = nhits = 0;
+            for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) {
+                nhits += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_HITS];
+                ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
+            }
+            if (getenv("PRF_DEBUG"))
+                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu rec_ovf_tiles %llu hit_ovf %llu ms %.4f\n",
+                        (unsigned long long)nhits, (unsigned long long)ncand,
+                        (unsigned long long)c->h_counters[PRF_CNT_REC_OVF], (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
+            const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
+            if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
+            if (!again) {
+                c->last_in_slabs = true;
+                c->last_ntiles = ntiles;
+            }
         } else {
+            // ---- generic path: candidates, then rows ----
+            int rc = ensure_buffers(c, want_cand, want_hits);
+            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+            HIPCHK(hipEventRecord(c->ev[0], c->stream));
             HIPCHK(prf_launch_scan_generic(c->stream, pl, 0, g->nwords - PRF_TILE_WORDS, kmin, kmax, min_repeats, min_span,
                                            c->d_cand, c->cand_cap, c->d_counters));
-        }
-        HIPCHK(hipEventRecord(c->ev[1], c->stream));
-        if (vs)
-            HIPCHK(prf_launch_verify_slabs(c->stream, pl, c->d_slabs, c->d_slab_counts, c->slab_cap, g->vp.tile_list,
-                                           g->vp.n_clean + g->vp.n_mixed, vs->waves, min_repeats, min_span, g->d_base,
-                                           (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
-        else
+            HIPCHK(hipEventRecord(c->ev[1], c->stream));
             HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base,
                                      (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
-        HIPCHK(hipEventRecord(c->ev[2], c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        ncand = c->h_counters[PRF_CNT_CAND];
-        nhits = c->h_counters[PRF_CNT_HITS];
-        const u64 slab_ovf = c->h_counters[PRF_CNT_SLAB_OVF];  // largest per-slab demand seen, 0 if none overflowed
-        bool again = false;
-        if (!vs && ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
-        if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
-        if (slab_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(slab_ovf + slab_ovf / 4 + 64, 1u << 24); again = true; }
+            HIPCHK(hipEventRecord(c->ev[2], c->stream));
+            HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
+            HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
+            launches = 2;
+            ncand = c->h_counters[PRF_CNT_CAND];
+            nhits = c->h_counters[PRF_CNT_HITS];
+            if (ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
+            if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
+            if (!again) c->last_in_slabs = false;
+        }
         if (!again) break;
     }
-    HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
-    HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
     c->last_nhits = nhits;
     if (stats) {
         stats->phase1_ms = ms01;
@@ -332,11 +406,15 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         stats->packed_bytes = (g->positions + 3) / 4;
         stats->n_candidates = ncand;
         stats->n_hits = nhits;
-        stats->n_launches = vs ? (g->vp.n_clean ? 1 : 0) + (g->vp.n_mixed ? 1 : 0) + 1 : 2;
+        stats->n_launches = launches;
         stats->path = vs ? 1 : 0;
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
     if (nhits == 0) return PRF_OK;
+    {
+        int rc = compact_last(c);
+        if (rc) return rc;
+    }
     prf_hit *rows = (prf_hit *)malloc(nhits * sizeof(prf_hit));
     if (!rows) return fail(PRF_ENOMEM, "prf_scan_genome: cannot allocate %llu rows", (unsigned long long)nhits);
     static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
@@ -381,6 +459,10 @@ int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, uint6
     if (!c || !n_rows || (capacity_rows && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
     HIPCHK(hipSetDevice(c->dev));
     *n_rows = c->last_nhits;
+    if (c->last_nhits) {
+        int rc = compact_last(c);
+        if (rc) return rc;
+    }
     const u64 n = std::min<u64>(c->last_nhits, capacity_rows);
     if (n) {
         HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));

@@ -5,7 +5,19 @@
 #include "prf_device.h"
 
 // device counter block (u64 each)
-enum { PRF_CNT_CAND = 0, PRF_CNT_HITS = 1, PRF_CNT_BADPOS = 2, PRF_CNT_SLAB_OVF = 3, PRF_CNT_N = 8 };
+enum {
+    PRF_CNT_CAND = 0,     // generic path: phase-1 candidates
+    PRF_CNT_HITS = 1,     // generic path: rows
+    PRF_CNT_BADPOS = 2,   // packer: first unsupported symbol
+    PRF_CNT_REC_OVF = 3,  // fused path: tiles whose LDS candidate list overflowed
+    PRF_CNT_HIT_OVF = 4,  // fused path: largest per-tile row demand above the slab capacity
+    PRF_CNT_SHARD0 = 8,   // fused path: per-shard sums, one 64-byte line per shard
+    PRF_CNT_NSHARD = 16,
+    PRF_CNT_SHARD_STRIDE = 8,
+    PRF_SH_HITS = 0,
+    PRF_SH_CAND = 1,
+    PRF_CNT_N = 8 + 16 * 8
+};
 
 hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
                                   u64 *bad_pos);
@@ -17,9 +29,5 @@ hipError_t prf_launch_scan_generic(hipStream_t s, const prf_planes &pl, u64 w_be
 hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *cand, u64 cand_cap, u32 min_repeats,
                              u32 min_span, const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap,
                              u64 *counters);
-
-hipError_t prf_launch_verify_slabs(hipStream_t s, const prf_planes &pl, const u64 *slabs, const u32 *slab_counts,
-                                   u32 slab_cap, const u32 *tile_list, u32 n_tiles, u32 nw, u32 min_repeats, u32 min_span,
-                                   const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap, u64 *counters);
 
 hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sink);

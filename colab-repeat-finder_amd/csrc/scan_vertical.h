@@ -1,9 +1,13 @@
-// scan_vertical.h -- host interface of the bit-sliced ("vertical") phase-1 kernel family.
+// scan_vertical.h -- host interface of the fused bit-sliced ("vertical") scan kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "prf_device.h"
 
-// Bit-sliced planes: see scan_vertical_impl.h for the layout.
+#define PRF_VMAX_K 480       // largest motif size the fused kernel takes (9-bit k field, LDS image width)
+#define PRF_VMAX_TASKS 96
+#define PRF_VMAX_WAVES 16
+
+// Bit-sliced planes: see scan_vertical.hip for the layout.
 struct prf_vplanes {
     u32 *VH = nullptr, *VL = nullptr, *VX = nullptr;
     unsigned char *tile_class = nullptr;  // per tile: 0 clean, 1 has not-ACGT positions in reach, 2 nothing but not-ACGT
@@ -12,25 +16,49 @@ struct prf_vplanes {
     u64 ntiles_alloc = 0;
 };
 
-struct prf_vspec {
-    u32 kmin, kmax, min_repeats, min_span;
-    u32 waves;     // waves (k-chunks) per tile workgroup
-    u32 launches;  // kernel launches per scan (upper bound)
-    int id;
+// One unit of scan work for one wave on one tile.
+//  kind 0     : "group" task -- the 8 motif sizes k0 .. k0+7 (k0 % 4 == 0) selected by `valid`, all with M(k) >= 15
+//  kind 1..14 : "exact" task -- the single motif size k0, whose minimum run length M(k0) equals `kind`
+struct prf_vtask {
+    unsigned short k0;
+    unsigned char kind;
+    unsigned char valid;
 };
 
-typedef hipError_t (*prf_vlaunch_fn)(hipStream_t, const prf_vplanes &, u64 *slabs, u32 *slab_counts, u32 slab_cap,
-                                     u64 *counters);
-struct prf_ventry {
-    prf_vspec spec;
-    prf_vlaunch_fn fn;
+// Work plan of one scan (host-built from kmin,kmax,min_repeats,min_span): tasks grouped per wave.
+struct prf_vplan {
+    u32 n_waves;                                // workgroup = 64 * n_waves threads
+    u32 n_tasks;
+    u32 wave_begin[PRF_VMAX_WAVES + 1];         // wave w runs tasks[wave_begin[w] .. wave_begin[w+1])
+    prf_vtask tasks[PRF_VMAX_TASKS];
+    u32 nc;                                     // virtual lanes of the LDS image (64 + extra)
+    u32 lds_bytes;
 };
 
-// returns the compiled specialisation for exactly these parameters, or nullptr (-> generic kernel)
-const prf_vspec *prf_vertical_find(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span);
+// everything the fused kernel needs (passed by value)
+struct prf_vscan_args {
+    const u32 *VH, *VL, *VX;       // bit-sliced planes
+    const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
+    const u32 *tile_list;          // clean tiles first, then mixed
+    u32 n_clean, n_mixed;
+    prf_hit_dev *hit_slabs;        // [tile][hit_cap]
+    u32 *hit_counts;               // [tile]
+    u32 hit_cap;
+    u32 min_repeats, min_span;
+    const u64 *contig_base;
+    u32 n_contigs;
+    u64 *counters;
+    prf_vplan plan;
+};
+
+// false if the parameters are outside what the fused kernel takes (-> generic kernel)
+bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vplan *plan);
 
 // ASCII (global coordinate space, G bytes) -> bit-sliced planes + tile classes + tile lists. Synchronises the stream.
 int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp);
 
-hipError_t prf_vertical_launch(hipStream_t s, const prf_vspec *vs, const prf_vplanes &vp, u64 *slabs, u32 *slab_counts,
-                               u32 slab_cap, u64 *counters);
+hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args);
+
+// rows of the per-tile slabs -> one compact array in tile order (exclusive scan of the counts + gather)
+hipError_t prf_launch_compact_hits(hipStream_t s, const prf_hit_dev *hit_slabs, const u32 *hit_counts, u32 hit_cap,
+                                   u64 ntiles, u64 *offsets, prf_hit_dev *out);

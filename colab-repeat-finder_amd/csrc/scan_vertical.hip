@@ -1,12 +1,414 @@
-// scan_vertical.hip -- registry of the compiled bit-sliced kernels + the ASCII -> bit-sliced packer.
-// The kernels themselves are in scan_vertical_impl.h, instantiated once per parameter set in
-// build/vspec_*.hip (generated by the Makefile from VSPECS).
+// scan_vertical.hip -- the fast path: fused bit-sliced ("vertical") scan + verification kernel for gfx950,
+// its work planner, the ASCII -> bit-sliced packer and the row compaction.
+//
+// What the kernel replaces: the L x n_k calls of PerfectRepeatTracker.advance()
+// (reference utils/perfect_repeat_tracker.py:43-61) AND the per-run filter/emit step (:71-101, :108-142),
+// for any kmin..kmax <= 480 and any thresholds with min_repeats >= 2, in ONE launch per scan.
+//
+// Layout.  A tile is 65536 consecutive positions, cut into 2048 streams of T = 32 positions.  Stream
+// s = bit*64 + lane lives in bit `bit` of lane `lane`: the 32-bit word W[t][lane] holds, in bit b,
+// position  tile*65536 + (b*64 + lane)*32 + t.  One wave-wide word row therefore advances 2048
+// independent streams by one position, and "position j+k" is simply row t+k of the same lane (or,
+// past the end of the stream, row (t+k)%32 of lane + (t+k)/32, because the next stream of a lane is the
+// same bit of the next lane).  Lanes 64.. of that virtual lane axis are the first lanes again, moved up
+// one bit, with bit 31 taken from the next tile; they are materialised once per tile in LDS.
+// In HBM a plane of a tile is stored [t/4][lane][t%4] so that one lane reads 4 rows with one 16-byte
+// access and a wave reads 1 KiB contiguously; the LDS image has the same shape with 64+J lanes.
+// The shift by k therefore costs no instruction: it is an LDS address.
+//
+// One workgroup (up to 4 waves) per tile, three steps:
+//  1. stage: the tile's bit-sliced planes and a window of the LINEAR H/L planes (tile - 64 .. tile + 65536 +
+//     1536 positions) go to LDS.
+//  2. scan: every wave runs its share of the plan's tasks (host-built, balanced by cost):
+//      * group task, 8 motif sizes k0..k0+7 with M(k) >= 15: a run of >= 15 matches contains an aligned
+//        group of 8 rows that all match.  Per (group, k) the 8 rows of (H^H')|(L^L') are OR-ed with 16
+//        v_bitop3_b32; a zero bit whose previous group was not all-match (or that is the first group of
+//        its stream) is a candidate.
+//      * exact task, one motif size with M(k) = M < 15 (templated on M): sliding OR over exactly M rows; a zero
+//        bit whose previous row is a mismatch (or that is row 0 of its stream) is a candidate.
+//     The loops over the four 8-row blocks of a stream are rolled and k0 is a run-time LDS offset, so the
+//     whole scan is a few KB of code that stays in the instruction cache (a fully unrolled per-parameter
+//     version measured 8x slower: 140 KB of straight-line code).
+//     Candidates leave the scan as 8-byte records (group position, k or k0, 8-bit mask of rows or k's)
+//     in a per-wave LDS list -- no atomics.  A wave whose list fills up verifies it on the spot.
+//  3. verify: all lanes expand the remaining records and turn each candidate into a row or nothing
+//     (verify_impl.h), reading the LDS window; rows go to the tile's slab in HBM.
+// Exactness argument: DESIGN.md.
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "prf_host.h"
 #include "scan_vertical.h"
+#include "verify_impl.h"
 
 namespace {
-constexpr int T = 32;
-constexpr int RG = T / 4;
+
+constexpr int T = 32;      // rows (= positions) per stream
+constexpr int RG = T / 4;  // row groups of 4 rows = one 16-byte slot per lane
+constexpr int LIN_PRE = 1;                                    // linear window: words before the tile
+constexpr int LIN_POST = 24;                                  // ... and after it
+constexpr int LW = (int)PRF_TILE_WORDS + LIN_PRE + LIN_POST;  // words per plane in the LDS window
+constexpr int REC_PER_WAVE = 256;                             // candidate records per wave (LDS list)
+constexpr int MAX_WAVES = 4;
+constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
+
+template <int A, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, A + I>{}), ...);
+}
+// f(integral_constant<int,i>) for i in [A, B)
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B > A) static_for_impl<A>(static_cast<F &&>(f), std::make_integer_sequence<int, B - A>{});
+}
+
+// ---- candidate records: [36:0] position/8, [37] kind, [46:38] k (START) or k0 (GROUP), [54:47] mask ----
+__device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
+    return (pos >> 3) | (kind << 37) | ((u64)k << 38) | ((u64)mask << 47);
+}
+
+// what the verification step needs about the tile
+struct TileCtx {
+    prf_window_view view;
+    prf_hit_dev *slab;        // this tile's row slab in HBM
+    u32 *hit_cnt;             // LDS
+    u32 hit_cap;
+    u32 min_repeats, min_span;
+    const u64 *contig_base;
+    u32 n_contigs;
+};
+
+// records [first, n) step `stride` of one list -> rows.  Returns the number of records this lane handled.
+__device__ __noinline__ u32 verify_records(const TileCtx &tc, const u64 *recs, u32 n, u32 first, u32 stride) {
+    u32 handled = 0;
+    for (u32 idx = first; idx < n; idx += stride) {
+        handled++;
+        const u64 rec = recs[idx];
+        const u64 p8 = (rec & ((1ull << 37) - 1ull)) << 3;
+        const u32 kind = (u32)(rec >> 37) & 1u;
+        const u32 kk = (u32)(rec >> 38) & 511u;
+        u32 mask = (u32)(rec >> 47) & 255u;
+        while (mask) {
+            const u32 bit = (u32)__builtin_ctz(mask);
+            mask &= mask - 1;
+            const u64 p = kind == (u32)PRF_KIND_GROUP ? p8 : p8 + bit;
+            const u32 k = kind == (u32)PRF_KIND_GROUP ? kk + bit : kk;
+            u64 a, b;
+            if (prf_candidate_to_run(tc.view, p, k, kind, tc.min_repeats, tc.min_span, a, b)) {
+                const u32 slot = atomicAdd(tc.hit_cnt, 1u);
+                if (slot < tc.hit_cap) {
+                    const u32 c = prf_contig_of(tc.contig_base, tc.n_contigs, a);
+                    prf_hit_dev h;
+                    h.start = a - tc.contig_base[c];
+                    h.end = b + k - tc.contig_base[c];
+                    h.k = k;
+                    h.contig = c;
+                    tc.slab[slot] = h;
+                }
+            }
+        }
+    }
+    return handled;
+}
+
+struct Emit {
+    u64 *recs;           // this wave's list in LDS, REC_PER_WAVE records
+    u32 cnt;             // records in it (wave-uniform)
+    u32 handled;         // records this lane verified in early flushes
+    u64 lane_pos;        // tile base + lane*32
+    int lane;
+    const TileCtx *tc;
+
+    // Every lane of the wave calls this together.  `hot`: bit b set = stream (lane, b) reports for the 8-row
+    // group starting at `row`; c[0..7] are the candidate words whose bit b forms the record's mask.
+    __device__ __forceinline__ void push(u32 hot, const u32 (&c)[8], int row, u64 kind, u32 k) {
+        u64 bal = __builtin_amdgcn_ballot_w64(hot != 0);
+        while (bal) {
+            const u32 n = (u32)__builtin_popcountll(bal);
+            if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
+                handled += verify_records(*tc, recs, cnt, (u32)lane, 64u);
+                cnt = 0;
+            }
+            if (hot) {
+                const u32 b = (u32)__builtin_ctz(hot);
+                hot &= hot - 1;
+                u32 mask = 0;
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mask |= ((c[i] >> b) & 1u) << i;
+                });
+                const u32 idx = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                recs[idx] = make_rec(lane_pos + (u64)b * (64u * T) + (u64)row, kind, k, mask);
+            }
+            cnt += n;
+            bal = __builtin_amdgcn_ballot_w64(hot != 0);
+        }
+    }
+};
+
+// v_bitop3_b32: any boolean function of three words in one VALU operation.  Truth-table operands:
+constexpr u32 TA = 0xF0, TB = 0xCC, TC = 0xAA;
+template <u32 TT>
+__device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+// acc | (b ^ c)
+__device__ __forceinline__ u32 or_xor(u32 acc, u32 b, u32 c) { return bitop3<(TA | (TB ^ TC)) & 0xFF>(acc, b, c); }
+// ~(a | b) & c
+__device__ __forceinline__ u32 nor_and(u32 a, u32 b, u32 c) { return bitop3<(~(TA | TB) & TC) & 0xFF>(a, b, c); }
+
+__device__ __forceinline__ void unpack4(u32 *dst, const uint4 v) {
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+
+// ---- group task: motif sizes k0 .. k0+7 (those in `valid`), all four 8-row blocks of the stream ----
+template <bool HASX>
+__device__ __forceinline__ void group_task(const uint4 *vimg, int nc, int lane, u32 k0, u32 valid, Emit &em) {
+    constexpr int NP = HASX ? 3 : 2;
+    u32 prev[8];
+    static_for<0, 8>([&](auto ic) { prev[decltype(ic)::value] = ~0u; });  // first group of a stream: report, verify decides
+#pragma unroll 1
+    for (int tb = 0; tb < 4; tb++) {
+        u32 a[3][8];   // rows 8tb .. 8tb+7
+        u32 w[3][16];  // rows 8tb+k0 .. 8tb+k0+15 (k0 % 4 == 0: whole 16-byte slots)
+        const int g0 = 2 * tb + (int)(k0 >> 2);
+        static_for<0, NP>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            static_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                unpack4(&a[p][4 * h], vimg[(p * RG + 2 * tb + h) * nc + lane]);
+            });
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                const int gg = g0 + g;
+                unpack4(&w[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+            });
+        });
+        u32 cand[8];
+        u32 hot = 0;
+        static_for<0, 8>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            u32 c = 0;
+            if ((valid >> kk) & 1u) {  // wave-uniform
+                // OR over the 8 rows of (H^H')|(L^L'): 16 operations, no per-row mismatch word
+                u32 o = a[0][0] ^ w[0][kk];
+                o = or_xor(o, a[1][0], w[1][kk]);
+                static_for<1, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    o = or_xor(o, a[0][i], w[0][kk + i]);
+                    o = or_xor(o, a[1][i], w[1][kk + i]);
+                });
+                if constexpr (HASX) {
+                    static_for<0, 8>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        o = o | a[2][i] | w[2][kk + i];
+                    });
+                }
+                c = ~o & prev[kk];  // all 8 rows match, the previous group did not (or is unknown)
+                prev[kk] = o;
+            }
+            cand[kk] = c;
+            hot |= c;
+        });
+        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, PRF_KIND_GROUP, k0);
+    }
+}
+
+// candidate word of row t (relative to the block): rows t .. t+M-1 all match and row t-1 does not.
+// m is indexed by row+1 (m[0] = the row before the block), o3[t] = OR of rows t..t+2.
+template <int M, int t, int LM, int LO>
+__device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO]) {
+    const u32 before = m[t];
+    if constexpr (M == 1) return ~m[t + 1] & before;
+    else if constexpr (M == 2) return nor_and(m[t + 1], m[t + 2], before);
+    else if constexpr (M == 3) return ~o3[t] & before;
+    else if constexpr (M <= 6) return nor_and(o3[t], o3[t + M - 3], before);
+    else if constexpr (M <= 9) return ~(o3[t] | o3[t + 3] | o3[t + M - 3]) & before;
+    else if constexpr (M <= 12) return nor_and(o3[t] | o3[t + 3] | o3[t + 6], o3[t + M - 3], before);
+    else return ~((o3[t] | o3[t + 3] | o3[t + 6]) | o3[t + 9] | o3[t + M - 3]) & before;
+}
+
+// ---- exact task: one motif size k whose minimum run length is M < 15; O = k % 4 ----
+template <int M, int O, bool HASX>
+__device__ __forceinline__ void exact_task(const uint4 *vimg, int nc, int lane, u32 k, Emit &em) {
+    constexpr int NP = HASX ? 3 : 2;
+    constexpr int NR = 8 + M - 1;          // mismatch words needed per block: rows t0 .. t0+NR-1
+    constexpr int NGB = (NR + 3) / 4;      // 16-byte slots of base rows
+    constexpr int NGS = (O + NR + 3) / 4;  // 16-byte slots of the rows shifted by k (first one starts O rows early)
+    u32 mprev = ~0u;  // mismatch word of the row before the block; unknown at row 0 -> report, verify decides
+#pragma unroll 1
+    for (int tb = 0; tb < 4; tb++) {
+        u32 a[3][4 * NGB];
+        u32 s[3][4 * NGS];
+        const int gs0 = 2 * tb + (int)(k >> 2);
+        static_for<0, NP>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            static_for<0, NGB>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                const int gg = 2 * tb + g;
+                unpack4(&a[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+            });
+            static_for<0, NGS>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                const int gg = gs0 + g;
+                unpack4(&s[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+            });
+        });
+        u32 m[NR + 1];
+        u32 o3[NR];
+        m[0] = mprev;
+        static_for<0, NR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            u32 v = or_xor(a[0][i] ^ s[0][O + i], a[1][i], s[1][O + i]);
+            if constexpr (HASX) v = v | a[2][i] | s[2][O + i];
+            m[i + 1] = v;
+        });
+        if constexpr (M >= 3) {
+            static_for<0, NR - 2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                o3[i] = m[i + 1] | m[i + 2] | m[i + 3];
+            });
+        }
+        u32 cand[8];
+        u32 hot = 0;
+        static_for<0, 8>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            cand[t] = start_word<M, t>(m, o3);
+            hot |= cand[t];
+        });
+        mprev = m[8];
+        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, PRF_KIND_START, k);
+    }
+}
+
+template <int M, bool HASX>
+__device__ __forceinline__ void exact_task_any(const uint4 *vimg, int nc, int lane, u32 k, Emit &em) {
+    switch (k & 3u) {  // wave-uniform
+        case 0: exact_task<M, 0, HASX>(vimg, nc, lane, k, em); break;
+        case 1: exact_task<M, 1, HASX>(vimg, nc, lane, k, em); break;
+        case 2: exact_task<M, 2, HASX>(vimg, nc, lane, k, em); break;
+        default: exact_task<M, 3, HASX>(vimg, nc, lane, k, em); break;
+    }
+}
+
+template <bool HASX>
+__device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &plan, int wave, int lane, Emit &em) {
+    const u32 t_end = plan.wave_begin[wave + 1];
+    const int nc = (int)plan.nc;
+    for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
+        const prf_vtask task = plan.tasks[ti];
+        switch (task.kind) {
+            case 0: group_task<HASX>(vimg, nc, lane, task.k0, task.valid, em); break;
+            case 1: exact_task_any<1, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 2: exact_task_any<2, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 3: exact_task_any<3, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 4: exact_task_any<4, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 5: exact_task_any<5, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 6: exact_task_any<6, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 7: exact_task_any<7, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 8: exact_task_any<8, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 9: exact_task_any<9, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 10: exact_task_any<10, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 11: exact_task_any<11, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 12: exact_task_any<12, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 13: exact_task_any<13, HASX>(vimg, nc, lane, task.k0, em); break;
+            default: exact_task_any<14, HASX>(vimg, nc, lane, task.k0, em); break;
+        }
+    }
+}
+
+// dynamic LDS: [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64][rec_cnt: MAX_WAVES u32][hit_cnt]
+extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
+
+__global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_args g) {
+    const int nc = (int)g.plan.nc;
+    uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem);
+    u64 *lin = reinterpret_cast<u64 *>(prf_smem + (size_t)3 * RG * nc * sizeof(uint4));
+    u64 *recs = lin + 2 * LW;
+    u32 *rec_cnt = reinterpret_cast<u32 *>(recs + MAX_WAVES * REC_PER_WAVE);
+    u32 *hit_cnt = rec_cnt + MAX_WAVES;
+
+    const int nt = (int)blockDim.x;
+    const int nw = nt >> 6;
+    const int tid = (int)threadIdx.x;
+    const u64 tile = g.tile_list[blockIdx.x];
+    const bool hasx = blockIdx.x >= g.n_clean;  // the list holds the clean tiles first
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int extra = nc - 64;
+
+    // ---- 1. stage ----
+    {
+        const uint4 *ph = reinterpret_cast<const uint4 *>(g.VH), *pL = reinterpret_cast<const uint4 *>(g.VL),
+                    *px = reinterpret_cast<const uint4 *>(g.VX);
+        const int np = hasx ? 3 : 2;
+        for (int idx = tid; idx < np * RG * 64; idx += nt) {
+            const int p = idx / (RG * 64), rg = (idx / 64) % RG, l = idx % 64;
+            const uint4 *src = p == 0 ? ph : (p == 1 ? pL : px);
+            const uint4 v = src[(tile * RG + rg) * 64 + l];
+            vimg[(p * RG + rg) * nc + l] = v;
+            if (l < extra) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
+                const uint4 nx = src[((tile + 1) * RG + rg) * 64 + l];
+                uint4 r;
+                r.x = (v.x >> 1) | (nx.x << 31);
+                r.y = (v.y >> 1) | (nx.y << 31);
+                r.z = (v.z >> 1) | (nx.z << 31);
+                r.w = (v.w >> 1) | (nx.w << 31);
+                vimg[(p * RG + rg) * nc + 64 + l] = r;
+            }
+        }
+        const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;  // the planes have readable padding in front
+        for (int idx = tid; idx < 2 * LW; idx += nt) {
+            const int p = idx / LW, j = idx % LW;
+            const u64 *src = p == 0 ? g.H : g.L;
+            lin[idx] = src[w0 + j];
+        }
+        if (tid == 0) *hit_cnt = 0;
+    }
+    __syncthreads();
+
+    TileCtx tc;
+    tc.view.lds = lin;
+    tc.view.w0 = tile * PRF_TILE_WORDS - LIN_PRE;
+    tc.view.nwords = LW;
+    tc.view.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
+    tc.view.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
+    tc.view.P[0] = g.H; tc.view.P[1] = g.L; tc.view.P[2] = g.X;
+    tc.slab = g.hit_slabs + tile * (u64)g.hit_cap;
+    tc.hit_cnt = hit_cnt;
+    tc.hit_cap = g.hit_cap;
+    tc.min_repeats = g.min_repeats;
+    tc.min_span = g.min_span;
+    tc.contig_base = g.contig_base;
+    tc.n_contigs = g.n_contigs;
+
+    // ---- 2. scan ----
+    Emit em;
+    em.recs = recs + wave * REC_PER_WAVE;
+    em.cnt = 0;
+    em.handled = 0;
+    em.lane_pos = tile * PRF_TILE + (u64)lane * T;
+    em.lane = lane;
+    em.tc = &tc;
+    if (hasx) run_tasks<true>(vimg, g.plan, wave, lane, em);
+    else run_tasks<false>(vimg, g.plan, wave, lane, em);
+    if (lane == 0) rec_cnt[wave] = em.cnt;
+    __syncthreads();
+
+    // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's slab, or nothing ----
+    u32 n_records = em.handled;
+    for (int w = 0; w < nw; w++) n_records += verify_records(tc, recs + w * REC_PER_WAVE, rec_cnt[w], (u32)tid, (u32)nt);
+    __syncthreads();
+    u64 *sh = g.counters + PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE;
+    if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
+    if (tid == 0) {
+        const u32 n = *hit_cnt;
+        g.hit_counts[tile] = n < g.hit_cap ? n : g.hit_cap;
+        atomicAdd(&sh[PRF_SH_HITS], (u64)n);
+        if (n > g.hit_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // ASCII -> bit-sliced planes.  One wave per tile; lane l, for bit b = 0..31, reads the 32 consecutive
@@ -63,31 +465,124 @@ __global__ void prf_tile_class_kernel(const unsigned char *__restrict__ any_all,
     cls[i] = (a & 2) ? 2 : (((a | b) & 1) ? 1 : 0);
 }
 
-}  // namespace
-
-#include <vector>
-
-#define PRF_VSPEC_X(KMIN, KMAX, R, SPAN) extern "C" prf_ventry prf_ventry_##KMIN##_##KMAX##_##R##_##SPAN;
-#include "vspec_list.inc"
-#undef PRF_VSPEC_X
-static const prf_ventry *const g_entries[] = {
-#define PRF_VSPEC_X(KMIN, KMAX, R, SPAN) &prf_ventry_##KMIN##_##KMAX##_##R##_##SPAN,
-#include "vspec_list.inc"
-#undef PRF_VSPEC_X
-};
-
-const prf_vspec *prf_vertical_find(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span) {
-    for (const prf_ventry *e : g_entries)
-        if (e->spec.kmin == kmin && e->spec.kmax == kmax && e->spec.min_repeats == min_repeats && e->spec.min_span == min_span)
-            return &e->spec;
-    return nullptr;
+// ---- rows of the per-tile slabs -> one compact array in tile order ----
+// exclusive scan of the per-tile counts by ONE workgroup (ntiles is at most a few 10^4), offsets[ntiles] = total
+__global__ __launch_bounds__(1024) void prf_scan_counts_kernel(const u32 *__restrict__ counts, u64 ntiles, u64 *__restrict__ offsets) {
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 per = (ntiles + 1023) / 1024;
+    const u64 lo = (u64)tid * per < ntiles ? (u64)tid * per : ntiles;
+    const u64 hi = lo + per < ntiles ? lo + per : ntiles;
+    u64 sum = 0;
+    for (u64 i = lo; i < hi; i++) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u64 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u64 run = part[tid] - sum;
+    for (u64 i = lo; i < hi; i++) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (tid == 1023) offsets[ntiles] = part[1023];
 }
 
-hipError_t prf_vertical_launch(hipStream_t s, const prf_vspec *vs, const prf_vplanes &vp, u64 *slabs, u32 *slab_counts,
-                               u32 slab_cap, u64 *counters) {
-    for (const prf_ventry *e : g_entries)
-        if (&e->spec == vs) return e->fn(s, vp, slabs, slab_counts, slab_cap, counters);
-    return hipErrorInvalidValue;
+__global__ __launch_bounds__(256) void prf_gather_hits_kernel(const prf_hit_dev *__restrict__ slabs, const u32 *__restrict__ counts,
+                                                              u32 hit_cap, const u64 *__restrict__ offsets,
+                                                              prf_hit_dev *__restrict__ out) {
+    const u64 tile = blockIdx.x;
+    const u32 n = counts[tile];
+    const prf_hit_dev *src = slabs + tile * (u64)hit_cap;
+    prf_hit_dev *dst = out + offsets[tile];
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace
+
+hipError_t prf_launch_compact_hits(hipStream_t s, const prf_hit_dev *hit_slabs, const u32 *hit_counts, u32 hit_cap,
+                                   u64 ntiles, u64 *offsets, prf_hit_dev *out) {
+    if (ntiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(prf_scan_counts_kernel, dim3(1), dim3(1024), 0, s, hit_counts, ntiles, offsets);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(prf_gather_hits_kernel, dim3((u32)ntiles), dim3(256), 0, s, hit_slabs, hit_counts, hit_cap, offsets, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Work plan: which wave runs which motif sizes.  Pure host code.
+bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vplan *plan) {
+    if (kmin < 1 || kmax < kmin || kmax > PRF_VMAX_K || min_repeats < 2) return false;
+    struct Item {
+        prf_vtask t;
+        u32 cost;
+    };
+    std::vector<Item> items;
+    u32 reach = 0;  // furthest row offset any task reads, relative to the first row of a block
+    u32 covered_to = 0;  // group chunks cover motif sizes below this
+    for (u32 k = kmin; k <= kmax; k++) {
+        const long long M = prf_min_matches(k, min_repeats, min_span);
+        if (M < SMALL_M) {
+            Item it;
+            it.t.k0 = (unsigned short)k;
+            it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
+            it.t.valid = 1;
+            it.cost = 40 + (u32)(8 + M - 1) * 12;  // per block: single-dword reads of the shifted rows + ~5 VALU per row
+            items.push_back(it);
+            reach = std::max<u32>(reach, k + 7 + (u32)M - 1);
+        } else if (k >= covered_to) {
+            const u32 k0 = k & ~3u;
+            u32 valid = 0;
+            for (u32 kk = 0; kk < 8; kk++) {
+                const u32 kx = k0 + kk;
+                if (kx >= kmin && kx <= kmax && prf_min_matches(kx, min_repeats, min_span) >= SMALL_M) valid |= 1u << kk;
+            }
+            Item it;
+            it.t.k0 = (unsigned short)k0;
+            it.t.kind = 0;
+            it.t.valid = (unsigned char)valid;
+            it.cost = 40 + 20 * (u32)__builtin_popcount(valid);
+            items.push_back(it);
+            reach = std::max<u32>(reach, k0 + 15);
+            covered_to = k0 + 8;
+        }
+    }
+    if (items.size() > PRF_VMAX_TASKS) return false;
+    // longest-processing-time-first assignment to at most 4 waves
+    u32 total = 0;
+    for (const Item &it : items) total += it.cost;
+    const u32 nw = std::max<u32>(1, std::min<u32>({4u, (u32)items.size(), (total + 199) / 200}));
+    std::vector<std::vector<Item>> bins(nw);
+    std::vector<u32> load(nw, 0);
+    std::vector<Item> sorted = items;
+    std::stable_sort(sorted.begin(), sorted.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+    for (const Item &it : sorted) {
+        const u32 w = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+        bins[w].push_back(it);
+        load[w] += it.cost;
+    }
+    plan->n_waves = nw;
+    plan->n_tasks = 0;
+    for (u32 w = 0; w < nw; w++) {
+        plan->wave_begin[w] = plan->n_tasks;
+        for (const Item &it : bins[w]) plan->tasks[plan->n_tasks++] = it.t;
+    }
+    for (u32 w = nw; w <= PRF_VMAX_WAVES; w++) plan->wave_begin[w] = plan->n_tasks;
+    plan->nc = 64 + (T - 1 + reach) / T + 1;
+    plan->lds_bytes = (u32)((size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
+                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (MAX_WAVES + 2) * sizeof(u32));
+    return true;
+}
+
+hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
+    const u32 n = args.n_clean + args.n_mixed;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(prf_vscan_kernel, dim3(n), dim3(64 * args.plan.n_waves), args.plan.lds_bytes, s, args);
+    return hipGetLastError();
 }
 
 int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp) {

@@ -1,93 +1,12 @@
-// verify.hip -- phase 2: one lane per phase-1 candidate.
-//
-// What it replaces: PerfectRepeatTracker.output_interval_if_it_passes_filters()
-// (reference utils/perfect_repeat_tracker.py:71-101) and consists_of_perfect_repeats() (:108-142),
-// in the closed form of SURVEY 3.4 (valid for min_repeats >= 2):
-//     a maximal run [a,b) of matches at period k is a row (a, b+k, k)  iff
-//     b-a >= M(k) = max((min_repeats-1)*k, min_span-k)  and  seq[a:a+k] is a primitive word.
-// The "N in motif" drop (:83) is implied: with M(k) >= k every position of [a, b+k) is a
-// non-N base.  The keep-shorter de-duplication (:94-96) is dead in this regime (Fine-Wilf).
+// verify.hip -- phase 2 of the generic path: one lane per phase-1 candidate (logic in verify_impl.h);
+// plus the streaming-read probe used for the measured HBM roofline.
 #include "prf_device.h"
 #include "prf_host.h"
+#include "verify_impl.h"
 
-// is seq[a : a+k] a whole number (>= 2) of copies of a shorter word?  A word of length k has a
-// proper divisor period iff it has period k/p for some prime p | k.
-__device__ bool prf_motif_is_repeat(const prf_planes &pl, u64 a, u32 k) {
-    u32 rest = k;
-    for (u32 p = 2; p <= rest; p++) {
-        if (rest % p) continue;
-        while (rest % p == 0) rest /= p;
-        const u32 d = k / p;      // candidate period
-        const u32 need = k - d;   // positions a .. a+need-1 must equal the ones d later
-        bool periodic = true;
-        for (u32 off = 0; off < need; off += 64) {
-            u64 mm = prf_mismatch64(pl, a + off, d);
-            const u32 left = need - off;
-            if (left < 64) mm &= (1ull << left) - 1ull;
-            if (mm) {
-                periodic = false;
-                break;
-            }
-        }
-        if (periodic) return true;
-    }
-    return false;
-}
-
-// one candidate -> zero or one row
-__device__ __forceinline__ void prf_process_candidate(const prf_planes &pl, u64 rec, u32 min_repeats, u32 min_span,
-                                                      const u64 *__restrict__ contig_base, u32 n_contigs,
-                                                      prf_hit_dev *__restrict__ hits, u64 hit_cap,
-                                                      u64 *__restrict__ counters) {
-    const u64 p = rec & ((1ull << PRF_CAND_POS_BITS) - 1ull);
-    const u32 k = (u32)((rec >> PRF_CAND_K_SHIFT) & 0xFFFFu);
-    const u32 kind = (u32)(rec >> PRF_CAND_KIND_SHIFT);
-    u64 a = p;
-    u64 scan_from = p;
-    if (kind == PRF_KIND_GROUP) {
-        // [p, p+8) all match.  This group is the run's leader iff [p-8, p) is not all-match;
-        // otherwise an earlier aligned group reports the same run.
-        if (p >= 8) {
-            const u64 mm = prf_mismatch64(pl, p - 8, k) & 0xFFull;
-            if (mm == 0) return;
-            a = p - (u64)__builtin_clzll(mm << 56);  // matches directly before p
-        }
-        scan_from = p + 8;
-    } else {
-        // exact start expected; a conservatively reported one may sit inside a run
-        if (p > 0 && (prf_mismatch64(pl, p - 1, k) & 1ull) == 0) return;
-    }
-    // extend right to the first mismatch (the guard gap guarantees one)
-    u64 b = scan_from;
-    for (;;) {
-        const u64 mm = prf_mismatch64(pl, b, k);
-        if (mm) {
-            b += (u64)__builtin_ctzll(mm);
-            break;
-        }
-        b += 64;
-    }
-    const long long M = prf_min_matches(k, min_repeats, min_span);
-    if ((long long)(b - a) < M) return;
-    if (prf_motif_is_repeat(pl, a, k)) return;
-    // contig lookup: last base <= a
-    u32 lo = 0, hi = n_contigs;
-    while (hi - lo > 1) {
-        const u32 mid = (lo + hi) >> 1;
-        if (contig_base[mid] <= a) lo = mid; else hi = mid;
-    }
-    const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
-    if (slot < hit_cap) {
-        prf_hit_dev h;
-        h.start = a - contig_base[lo];
-        h.end = b + k - contig_base[lo];
-        h.k = k;
-        h.contig = lo;
-        hits[slot] = h;
-    }
-}
-
-// candidates in one flat array (generic phase 1)
+// candidates in one flat array (generic phase 1).  own_lo/own_hi restrict the rows to those "owned" by a
+// position range, with the ownership rule of the fused kernel (first aligned all-match group of 8 for k with
+// M(k) >= 15, the run start otherwise): used when single tiles are re-done by the generic path.
 __global__ __launch_bounds__(256) void prf_verify_kernel(prf_planes pl, const u64 *__restrict__ cand, u64 cand_cap,
                                                          u32 min_repeats, u32 min_span,
                                                          const u64 *__restrict__ contig_base, u32 n_contigs,
@@ -95,30 +14,27 @@ __global__ __launch_bounds__(256) void prf_verify_kernel(prf_planes pl, const u6
                                                          u64 *__restrict__ counters) {
     u64 n = counters[PRF_CNT_CAND];
     if (n > cand_cap) n = cand_cap;  // overflow is reported to the host, which re-runs with a larger buffer
+    prf_global_view view;
+    view.P[0] = pl.H; view.P[1] = pl.L; view.P[2] = pl.X;
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        prf_process_candidate(pl, cand[i], min_repeats, min_span, contig_base, n_contigs, hits, hit_cap, counters);
-}
-
-// candidates in per-(tile, wave) slabs (bit-sliced phase 1): one wave per slab
-__global__ __launch_bounds__(256) void prf_verify_slabs_kernel(prf_planes pl, const u64 *__restrict__ slabs,
-                                                               const u32 *__restrict__ slab_counts, u32 slab_cap,
-                                                               const u32 *__restrict__ tile_list, u32 n_units, u32 nw,
-                                                               u32 min_repeats, u32 min_span,
-                                                               const u64 *__restrict__ contig_base, u32 n_contigs,
-                                                               prf_hit_dev *__restrict__ hits, u64 hit_cap,
-                                                               u64 *__restrict__ counters) {
-    const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n_units) return;
-    const u32 lane = threadIdx.x & 63;
-    const u64 unit = (u64)tile_list[i / nw] * nw + (i % nw);
-    u32 n = slab_counts[unit];
-    if (n == 0) return;
-    if (lane == 0) atomicAdd(&counters[PRF_CNT_CAND], (u64)n);
-    if (n > slab_cap) n = slab_cap;  // overflow: the host re-runs with larger slabs
-    const u64 *slab = slabs + unit * slab_cap;
-    for (u32 j = lane; j < n; j += 64)
-        prf_process_candidate(pl, slab[j], min_repeats, min_span, contig_base, n_contigs, hits, hit_cap, counters);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 rec = cand[i];
+        const u64 p = rec & ((1ull << PRF_CAND_POS_BITS) - 1ull);
+        const u32 k = (u32)((rec >> PRF_CAND_K_SHIFT) & 0xFFFFu);
+        const u32 kind = (u32)(rec >> PRF_CAND_KIND_SHIFT);
+        u64 a, b;
+        if (!prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b)) continue;
+        const u32 c = prf_contig_of(contig_base, n_contigs, a);
+        const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
+        if (slot < hit_cap) {
+            prf_hit_dev h;
+            h.start = a - contig_base[c];
+            h.end = b + k - contig_base[c];
+            h.k = k;
+            h.contig = c;
+            hits[slot] = h;
+        }
+    }
 }
 
 hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *cand, u64 cand_cap, u32 min_repeats,
@@ -126,16 +42,6 @@ hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *can
                              u64 *counters) {
     hipLaunchKernelGGL(prf_verify_kernel, dim3(1024), dim3(256), 0, s, pl, cand, cand_cap, min_repeats, min_span,
                        contig_base, n_contigs, hits, hit_cap, counters);
-    return hipGetLastError();
-}
-
-hipError_t prf_launch_verify_slabs(hipStream_t s, const prf_planes &pl, const u64 *slabs, const u32 *slab_counts,
-                                   u32 slab_cap, const u32 *tile_list, u32 n_tiles, u32 nw, u32 min_repeats, u32 min_span,
-                                   const u64 *contig_base, u32 n_contigs, prf_hit_dev *hits, u64 hit_cap, u64 *counters) {
-    const u32 n_units = n_tiles * nw;
-    if (n_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(prf_verify_slabs_kernel, dim3((n_units + 3) / 4), dim3(256), 0, s, pl, slabs, slab_counts, slab_cap,
-                       tile_list, n_units, nw, min_repeats, min_span, contig_base, n_contigs, hits, hit_cap, counters);
     return hipGetLastError();
 }
 

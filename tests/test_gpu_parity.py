@@ -101,13 +101,15 @@ def test_generic_kernel_param_sweep_vs_oracle(ctx):
 
 
 VSPECS = [(1, 50, 3, 9), (1, 100, 3, 9), (2, 6, 3, 9), (1, 6, 3, 9), (1, 7, 3, 6), (2, 10, 3, 6), (1, 10, 3, 6),
-          (1, 20, 3, 12), (1, 10, 3, 7), (5, 64, 2, 1), (1, 30, 2, 20)]
+          (1, 20, 3, 12), (1, 10, 3, 7), (5, 64, 2, 1), (1, 30, 2, 20), (3, 3, 2, 100), (17, 17, 5, 1), (1, 130, 4, 30),
+          (63, 65, 2, 5), (7, 9, 2, 1), (1, 14, 2, 2), (30, 130, 2, 200), (2, 40, 6, 60)]
 
 
-def test_bit_sliced_kernel_every_compiled_spec_vs_oracle_and_generic(ctx):
-    """The bit-sliced (vertical) kernel, for every parameter set it is compiled for, against the oracle and
-    against the generic kernel; the input has N blocks that start and end inside tiles, so both the clean
-    and the not-ACGT tile variants run, and planted repeats that cross stream and tile edges."""
+def test_fused_bit_sliced_kernel_param_sweep_vs_oracle_and_generic(ctx):
+    """The fused bit-sliced (vertical) kernel over many parameter sets (exact tasks for every M 1..14, group
+    tasks, ranges that mix both), against the oracle and against the generic kernel; the input has N blocks
+    that start and end inside tiles, so both the clean and the not-ACGT tile variants run, and planted
+    repeats that cross stream and tile edges."""
     import prf_native
     import synth
     seq = bytearray(synth.chr_standin(length=700_000, seed=5, n_head=70_000, n_tail=3_000, repeats_per_mbp=5000).tobytes())
@@ -131,15 +133,30 @@ def test_bit_sliced_kernel_every_compiled_spec_vs_oracle_and_generic(ctx):
         g.free()
 
 
-def test_bit_sliced_kernel_slab_overflow_and_long_runs(ctx):
-    """An all-A contig is one run for every k: every stream start is a (spurious) candidate, the candidate
-    slabs overflow and the scan must grow them and still return the exact rows."""
+def test_very_long_runs_flush_the_candidate_lists(ctx):
+    """An all-A contig is one run for every k: every stream start inside it is a (spurious) candidate, the
+    per-wave candidate lists of the fused kernel fill up over and over and are verified on the spot; the
+    single real row per k is found by a walk of 300 000 positions."""
     seq = b"A" * 300_000 + b"C" + b"GT" * 40_000
     rows, stats = ctx.scan([seq], 1, 50, 3, 9)
     assert stats.path == 1
     got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
     assert got == [(0, 300_000, 1), (300_001, 380_001, 2)]
     assert stats.n_candidates > 100_000
+
+
+def test_row_slab_overflow_grows_the_slabs(ctx):
+    """More rows in one tile than the default per-tile row slab holds (512) but fewer candidate records than
+    the LDS list (1024): the scan must grow the slabs and retry on the fused path."""
+    import collections
+    unit = b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG"
+    seq = unit * 2500
+    rows, stats = ctx.scan([seq], 1, 6, 3, 9)
+    assert stats.path == 1
+    got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+    assert got == oracle_rows(seq, 1, 6, 3, 9)
+    per_tile = collections.Counter(s // 65536 for s, _e, _k in got)
+    assert max(per_tile.values()) > 512
 
 
 def test_errors_cross_the_boundary_cleanly(ctx):
