@@ -348,6 +348,12 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.min_repeats = min_repeats; a.min_span = min_span;
             a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
             a.counters = c->d_counters;
+            a.dbg = nullptr;
+#ifdef PRF_STAMPS
+            static u64 *dbg_buf = nullptr;
+            if (!dbg_buf) HIPCHK(hipMalloc((void **)&dbg_buf, (size_t)(1 << 20) * 32 * sizeof(u64)));
+            a.dbg = dbg_buf;
+#endif
             HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
             HIPCHK(prf_vertical_launch(c->stream, a));
@@ -362,6 +368,14 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 nhits += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_HITS];
                 ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
             }
+#ifdef PRF_STAMPS
+            if (const char *path = getenv("PRF_STAMPS_OUT")) {
+                const size_t nu = (size_t)(a.n_clean + a.n_mixed) * 4 * 8;
+                std::vector<u64> host(nu);
+                HIPCHK(hipMemcpy(host.data(), a.dbg, nu * sizeof(u64), hipMemcpyDeviceToHost));
+                if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, nu, f); fclose(f); }
+            }
+#endif
             if (getenv("PRF_DEBUG"))
                 fprintf(stderr, "[prf] fused: hits %llu cand-records %llu rec_ovf_tiles %llu hit_ovf %llu ms %.4f\n",
                         (unsigned long long)nhits, (unsigned long long)ncand,

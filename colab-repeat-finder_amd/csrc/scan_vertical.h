@@ -48,6 +48,7 @@ struct prf_vscan_args {
     const u64 *contig_base;
     u32 n_contigs;
     u64 *counters;
+    u64 *dbg;                      // diagnostic (PRF_STAMPS) builds only; nullptr otherwise
     prf_vplan plan;
 };
 

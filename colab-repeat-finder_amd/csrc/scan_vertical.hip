@@ -42,6 +42,17 @@
 #include "scan_vertical.h"
 #include "verify_impl.h"
 
+// Diagnostic build only (make STAMPS=1 -> libprf_stamps.so): per-wave s_memtime stamps at the phase
+// boundaries, written to a debug buffer that nothing else reads.  The product build has no stamp.
+#ifdef PRF_STAMPS
+#define PRF_STAMP(i)                                                                          \
+    do {                                                                                      \
+        if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PRF_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int T = 32;      // rows (= positions) per stream
@@ -68,23 +79,56 @@ __device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
     return (pos >> 3) | (kind << 37) | ((u64)k << 38) | ((u64)mask << 47);
 }
 
-// what the verification step needs about the tile
+// dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
+extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
+constexpr int SMEM_HDR = 192;
+
+// what the verification step needs about the tile; lives at the start of LDS (filled by thread 0 while staging)
 struct TileCtx {
-    prf_window_view view;
+    u64 w0;                   // first word of the linear window
+    u64 xz_lo, xz_hi;         // positions known to hold no not-ACGT symbol
+    const u64 *H, *L, *X;     // linear planes in HBM
     prf_hit_dev *slab;        // this tile's row slab in HBM
-    u32 *hit_cnt;             // LDS
+    u64 contig_base;          // a tile lies inside one contig
+    u32 contig;
     u32 hit_cap;
     u32 min_repeats, min_span;
-    const u64 *contig_base;
-    u32 n_contigs;
+    u32 lin_off;              // byte offset of the linear window in LDS
 };
+static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 
-// records [first, n) step `stride` of one list -> rows.  Returns the number of records this lane handled.
-__device__ __noinline__ u32 verify_records(const TileCtx &tc, const u64 *recs, u32 n, u32 first, u32 stride) {
+__device__ __forceinline__ u32 *smem_rec_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128); }
+__device__ __forceinline__ u32 *smem_hit_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128 + 4 * MAX_WAVES); }
+
+// Candidate records -> rows.  only_list >= 0: the records [0, n) of that wave's list, taken by lanes
+// first, first+stride, ... (a wave emptying its own full list in the middle of the scan).  only_list < 0:
+// the records of all lists, as one index space [0, n) (the cooperative pass at the end of the tile).
+// Returns the number of records this lane handled.  Not inlined: called from two places.
+__device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
+    prf_window_view view;
+    view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
+    view.w0 = tc.w0;
+    view.nwords = LW;
+    view.xz_lo = tc.xz_lo;
+    view.xz_hi = tc.xz_hi;
+    view.P[0] = tc.H; view.P[1] = tc.L; view.P[2] = tc.X;
+    const u32 min_repeats = tc.min_repeats, min_span = tc.min_span, hit_cap = tc.hit_cap, contig = tc.contig;
+    const u64 contig_base = tc.contig_base;
+    prf_hit_dev *slab = tc.slab;
+    u32 *hit_cnt = smem_hit_cnt();
+    const u32 *rec_cnt = smem_rec_cnt();
+    const u32 c0 = rec_cnt[0], c1 = c0 + rec_cnt[1], c2 = c1 + rec_cnt[2];
     u32 handled = 0;
     for (u32 idx = first; idx < n; idx += stride) {
         handled++;
-        const u64 rec = recs[idx];
+        u32 slot_idx;
+        if (only_list >= 0) slot_idx = (u32)only_list * REC_PER_WAVE + idx;
+        else if (idx < c0) slot_idx = idx;
+        else if (idx < c1) slot_idx = REC_PER_WAVE + (idx - c0);
+        else if (idx < c2) slot_idx = 2 * REC_PER_WAVE + (idx - c1);
+        else slot_idx = 3 * REC_PER_WAVE + (idx - c2);
+        const u64 rec = recs[slot_idx];
         const u64 p8 = (rec & ((1ull << 37) - 1ull)) << 3;
         const u32 kind = (u32)(rec >> 37) & 1u;
         const u32 kk = (u32)(rec >> 38) & 511u;
@@ -95,16 +139,15 @@ __device__ __noinline__ u32 verify_records(const TileCtx &tc, const u64 *recs, u
             const u64 p = kind == (u32)PRF_KIND_GROUP ? p8 : p8 + bit;
             const u32 k = kind == (u32)PRF_KIND_GROUP ? kk + bit : kk;
             u64 a, b;
-            if (prf_candidate_to_run(tc.view, p, k, kind, tc.min_repeats, tc.min_span, a, b)) {
-                const u32 slot = atomicAdd(tc.hit_cnt, 1u);
-                if (slot < tc.hit_cap) {
-                    const u32 c = prf_contig_of(tc.contig_base, tc.n_contigs, a);
+            if (prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b)) {
+                const u32 slot = atomicAdd(hit_cnt, 1u);
+                if (slot < hit_cap) {
                     prf_hit_dev h;
-                    h.start = a - tc.contig_base[c];
-                    h.end = b + k - tc.contig_base[c];
+                    h.start = a - contig_base;
+                    h.end = b + k - contig_base;
                     h.k = k;
-                    h.contig = c;
-                    tc.slab[slot] = h;
+                    h.contig = contig;
+                    slab[slot] = h;
                 }
             }
         }
@@ -114,11 +157,12 @@ __device__ __noinline__ u32 verify_records(const TileCtx &tc, const u64 *recs, u
 
 struct Emit {
     u64 *recs;           // this wave's list in LDS, REC_PER_WAVE records
+    u64 *all_recs;       // all lists
+    int wave;
     u32 cnt;             // records in it (wave-uniform)
     u32 handled;         // records this lane verified in early flushes
     u64 lane_pos;        // tile base + lane*32
     int lane;
-    const TileCtx *tc;
 
     // Every lane of the wave calls this together.  `hot`: bit b set = stream (lane, b) reports for the 8-row
     // group starting at `row`; c[0..7] are the candidate words whose bit b forms the record's mask.
@@ -127,7 +171,7 @@ struct Emit {
         while (bal) {
             const u32 n = (u32)__builtin_popcountll(bal);
             if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
-                handled += verify_records(*tc, recs, cnt, (u32)lane, 64u);
+                handled += verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
                 cnt = 0;
             }
             if (hot) {
@@ -318,19 +362,16 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &pl
     }
 }
 
-// dynamic LDS: [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64][rec_cnt: MAX_WAVES u32][hit_cnt]
-extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
-
 __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_args g) {
     const int nc = (int)g.plan.nc;
-    uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem);
-    u64 *lin = reinterpret_cast<u64 *>(prf_smem + (size_t)3 * RG * nc * sizeof(uint4));
+    uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem + SMEM_HDR);
+    const u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)3 * RG * nc * sizeof(uint4));
+    u64 *lin = reinterpret_cast<u64 *>(prf_smem + lin_off);
     u64 *recs = lin + 2 * LW;
-    u32 *rec_cnt = reinterpret_cast<u32 *>(recs + MAX_WAVES * REC_PER_WAVE);
-    u32 *hit_cnt = rec_cnt + MAX_WAVES;
+    u32 *rec_cnt = smem_rec_cnt();
+    u32 *hit_cnt = smem_hit_cnt();
 
     const int nt = (int)blockDim.x;
-    const int nw = nt >> 6;
     const int tid = (int)threadIdx.x;
     const u64 tile = g.tile_list[blockIdx.x];
     const bool hasx = blockIdx.x >= g.n_clean;  // the list holds the clean tiles first
@@ -338,6 +379,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     const int lane = tid & 63;
     const int extra = nc - 64;
 
+    PRF_STAMP(0);
     // ---- 1. stage ----
     {
         const uint4 *ph = reinterpret_cast<const uint4 *>(g.VH), *pL = reinterpret_cast<const uint4 *>(g.VL),
@@ -364,42 +406,52 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             const u64 *src = p == 0 ? g.H : g.L;
             lin[idx] = src[w0 + j];
         }
-        if (tid == 0) *hit_cnt = 0;
+        if (tid < MAX_WAVES) rec_cnt[tid] = 0;
+        if (tid == 0) {
+            *hit_cnt = 0;
+            TileCtx tc;
+            tc.w0 = tile * PRF_TILE_WORDS - LIN_PRE;
+            tc.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
+            tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
+            tc.H = g.H; tc.L = g.L; tc.X = g.X;
+            tc.slab = g.hit_slabs + tile * (u64)g.hit_cap;
+            // contigs start on tile boundaries, so every run that this tile reports lies in the tile's contig
+            tc.contig = prf_contig_of(g.contig_base, g.n_contigs, tile * PRF_TILE);
+            tc.contig_base = g.contig_base[tc.contig];
+            tc.hit_cap = g.hit_cap;
+            tc.min_repeats = g.min_repeats;
+            tc.min_span = g.min_span;
+            tc.lin_off = lin_off;
+            *reinterpret_cast<TileCtx *>(prf_smem) = tc;
+        }
     }
+    PRF_STAMP(1);
     __syncthreads();
-
-    TileCtx tc;
-    tc.view.lds = lin;
-    tc.view.w0 = tile * PRF_TILE_WORDS - LIN_PRE;
-    tc.view.nwords = LW;
-    tc.view.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
-    tc.view.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
-    tc.view.P[0] = g.H; tc.view.P[1] = g.L; tc.view.P[2] = g.X;
-    tc.slab = g.hit_slabs + tile * (u64)g.hit_cap;
-    tc.hit_cnt = hit_cnt;
-    tc.hit_cap = g.hit_cap;
-    tc.min_repeats = g.min_repeats;
-    tc.min_span = g.min_span;
-    tc.contig_base = g.contig_base;
-    tc.n_contigs = g.n_contigs;
+    PRF_STAMP(2);
 
     // ---- 2. scan ----
     Emit em;
     em.recs = recs + wave * REC_PER_WAVE;
+    em.all_recs = recs;
+    em.wave = wave;
     em.cnt = 0;
     em.handled = 0;
     em.lane_pos = tile * PRF_TILE + (u64)lane * T;
     em.lane = lane;
-    em.tc = &tc;
     if (hasx) run_tasks<true>(vimg, g.plan, wave, lane, em);
     else run_tasks<false>(vimg, g.plan, wave, lane, em);
-    if (lane == 0) rec_cnt[wave] = em.cnt;
+    if (lane == 0) rec_cnt[wave] = em.cnt;  // waves the plan does not use keep the 0 from staging
+    PRF_STAMP(3);
     __syncthreads();
+    PRF_STAMP(4);
 
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's slab, or nothing ----
-    u32 n_records = em.handled;
-    for (int w = 0; w < nw; w++) n_records += verify_records(tc, recs + w * REC_PER_WAVE, rec_cnt[w], (u32)tid, (u32)nt);
+    u32 total = 0;
+    for (int w = 0; w < MAX_WAVES; w++) total += rec_cnt[w];
+    const u32 n_records = em.handled + verify_records((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);
+    PRF_STAMP(5);
     __syncthreads();
+    PRF_STAMP(6);
     u64 *sh = g.counters + PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE;
     if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
     if (tid == 0) {
@@ -573,8 +625,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     }
     for (u32 w = nw; w <= PRF_VMAX_WAVES; w++) plan->wave_begin[w] = plan->n_tasks;
     plan->nc = 64 + (T - 1 + reach) / T + 1;
-    plan->lds_bytes = (u32)((size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
-                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (MAX_WAVES + 2) * sizeof(u32));
+    plan->lds_bytes = (u32)(SMEM_HDR + (size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
+                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64));
     return true;
 }
 

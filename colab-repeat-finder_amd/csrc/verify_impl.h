@@ -17,14 +17,22 @@
 struct prf_global_view {
     const u64 *P[3];
     __device__ __forceinline__ u64 bits(int plane, u64 q) const { return prf_bits_at(P[plane], q); }
+    // mismatch bits (1 = differs, or either side is not ACGT) of positions q .. q+63 against q+k ..
+    __device__ __forceinline__ u64 mismatch64(u64 q, u32 k) const {
+        const u64 h = bits(0, q) ^ bits(0, q + k);
+        const u64 l = bits(1, q) ^ bits(1, q + k);
+        const u64 x = bits(2, q) | bits(2, q + k);
+        return h | l | x;
+    }
 };
 
 // a window of the H and L linear planes staged in LDS ([plane][nwords], first word = global word w0);
 // positions outside the window fall through to global memory.  The not-ACGT plane X is not staged: it
 // is known to be zero on [xz_lo, xz_hi) (a clean tile and its successor) and read from global memory
 // elsewhere (the 64 positions in front of the tile; tiles with N in them).
+typedef __attribute__((address_space(3))) const u64 prf_lds_cu64;  // explicitly LDS: ds_read, not flat_load
 struct prf_window_view {
-    const u64 *lds;
+    prf_lds_cu64 *lds;
     u64 w0;
     u32 nwords;
     u64 xz_lo, xz_hi;
@@ -37,19 +45,30 @@ struct prf_window_view {
         const u64 rel = (q >> 6) - w0;  // wraps to a huge value below the window
         const unsigned s = (unsigned)(q & 63);
         if (rel + 1 < (u64)nwords) {
-            const u64 *p = lds + (u32)plane * nwords + (u32)rel;
+            prf_lds_cu64 *p = lds + (u32)plane * nwords + (u32)rel;
             return prf_fsr(p[0], p[1], s);
         }
         return prf_bits_at(P[plane], q);
+    }
+    __device__ __forceinline__ u64 mismatch64(u64 q, u32 k) const {
+        // common case: both 64-position looks lie inside the LDS window and inside the N-free range
+        const u64 ra = (q >> 6) - w0, rb = ((q + k) >> 6) - w0;
+        if (ra + 1 < (u64)nwords && rb + 1 < (u64)nwords && q >= xz_lo && q + k + 64 <= xz_hi) {
+            const unsigned sa = (unsigned)(q & 63), sb = (unsigned)((q + k) & 63);
+            prf_lds_cu64 *ha = lds + (u32)ra, *hb = lds + (u32)rb;
+            prf_lds_cu64 *la = ha + nwords, *lb = hb + nwords;
+            return (prf_fsr(ha[0], ha[1], sa) ^ prf_fsr(hb[0], hb[1], sb)) | (prf_fsr(la[0], la[1], sa) ^ prf_fsr(lb[0], lb[1], sb));
+        }
+        const u64 h = bits(0, q) ^ bits(0, q + k);
+        const u64 l = bits(1, q) ^ bits(1, q + k);
+        const u64 x = bits(2, q) | bits(2, q + k);
+        return h | l | x;
     }
 };
 
 template <class View>
 __device__ __forceinline__ u64 prf_vmismatch64(const View &v, u64 q, u32 k) {
-    const u64 h = v.bits(0, q) ^ v.bits(0, q + k);
-    const u64 l = v.bits(1, q) ^ v.bits(1, q + k);
-    const u64 x = v.bits(2, q) | v.bits(2, q + k);
-    return h | l | x;
+    return v.mismatch64(q, k);
 }
 
 // does seq[a : a+k] have period d (d < k)?

@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprf.so")
+LIB_PATH = os.environ.get("PRF_LIB", os.path.join(_HERE, "libprf.so"))  # PRF_LIB: diagnostic builds only
 
 PRF_OK = 0
 PRF_EINVAL = -1

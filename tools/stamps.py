@@ -1,0 +1,22 @@
+"""Diagnostic: per-wave phase times of the fused kernel from the PRF_STAMPS build (libprf_stamps.so).
+Usage (GPU box): PRF_LIB=colab-repeat-finder_amd/libprf_stamps.so PRF_STAMPS_OUT=/tmp/st.bin python tools/stamps.py [length]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, 'colab-repeat-finder_amd'); sys.path.insert(0, '.')
+import prf_native, synth
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 50_818_468
+seq = synth.chr_standin(length=L, seed=22, n_head=10_510_000 if L > 2e7 else L // 10, n_tail=10_000).tobytes()
+ctx = prf_native.Context(0)
+g = ctx.load([seq], 50)
+for _ in range(3):
+    g.scan(1, 50, 3, 9, fetch=False)
+_, st = g.scan(1, 50, 3, 9, fetch=False)
+print('kernel ms', st.phase1_ms)
+d = np.fromfile(os.environ['PRF_STAMPS_OUT'], dtype=np.uint64).reshape(-1, 4, 8).astype(np.int64)
+t0 = d[:, :, 0].min()
+names = ['stage', 'bar1', 'scan', 'bar2', 'verify', 'bar3']
+for w in range(4):
+    seg = [np.median(d[:, w, i + 1] - d[:, w, i]) for i in range(6)]
+    print('wave', w, ' '.join(f'{n}={int(v)}' for n, v in zip(names, seg)), 'total', int(np.median(d[:, w, 6] - d[:, w, 0])))
+print('WG start spread (cycles): min', 0, 'median', int(np.median(d[:, 0, 0] - t0)), 'max', int((d[:, 0, 0] - t0).max()))
+print('WG end   (cycles): median', int(np.median(d[:, :, 6].max(axis=1) - t0)), 'max', int((d[:, :, 6].max(axis=1) - t0).max()))
