@@ -35,6 +35,23 @@ for p in (ROOT, PKG):
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
+def pmc_traffic(length, kmin, kmax):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    None if no committed measurement matches this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            for rec in json.load(f):
+                if rec["length"] == length and rec["kmin"] == kmin and rec["kmax"] == kmax:
+                    return rec["hbm_bytes_per_launch"]
+    except (ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(seq_bytes, kmin, kmax, min_repeats, min_span, sample_bp):
     """Oracle (kind 'port': C restatement of the reference's state machine), 1 thread, bounded sample."""
     from oracle import prf_oracle
@@ -159,8 +176,9 @@ def main():
                        "multi_gpu": "one contig per rank, no data-path collective; one padded RCCL gather of rows to rank 0"
                                     if world > 1 else "n/a"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "kernel": "phase-1 scan kernel", "kernel_ms": round(p1, 5),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(length, args.kmin, args.kmax),
+                         "kernel": "prf_vscan_kernel (fused scan + verify)" if st0.path == 1 else "prf_scan_generic_kernel",
+                         "kernel_ms": round(p1, 5),
                          "algorithmic_bytes_per_launch": bytes_alg,
                          "measured_hbm_read_GBps": round(hbm_meas, 1),
                          "frac_of_measured_read": round(achieved / hbm_meas, 5)},

@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of the scan: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests), contigs as the unit of work, no data-path collective.
+
+The reference's only parallel strategy is file-level interval sharding in a cloud batch pipeline whose outputs
+are concatenated with `cat | sort | uniq` and repaired by merge_loci (reference
+hail_batch_pipeline/run_hail_batch_pipeline.py:76-77, :151-153, :170-175).  Here contigs are dealt to the ranks
+(longest first, to the least loaded rank), every rank scans its own contigs with its own libprf context, and the
+rows -- tiny compared with the input -- are concatenated on rank 0 with ONE padded gather.  Because per-contig
+scans are independent the result is exactly the single-GPU result; nothing has to be repaired.
+"""
+import numpy as np
+
+ROW_DTYPE = np.dtype([("start", "<u8"), ("end", "<u8"), ("k", "<u4"), ("contig", "<u4")])
+
+
+def plan_contig_shards(lengths, world):
+    """Longest-processing-time-first: returns, per rank, the sorted list of contig indices it scans."""
+    shards = [[] for _ in range(world)]
+    load = [0] * world
+    for idx in sorted(range(len(lengths)), key=lambda i: (-lengths[i], i)):
+        r = min(range(world), key=lambda j: (load[j], j))
+        shards[r].append(idx)
+        load[r] += lengths[idx]
+    return [sorted(s) for s in shards]
+
+
+def rows_to_tensor(rows, capacity, torch, device):
+    """(capacity+1, 3) int64 tensor: 24-byte rows as three int64 words, the row count in the last row."""
+    t = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)
+    n = len(rows)
+    if n:
+        flat = np.ascontiguousarray(rows).view(np.int64).reshape(n, 3)
+        t[:n] = torch.from_numpy(flat.copy()).to(device)
+    t[capacity, 0] = n
+    return t
+
+
+def tensor_to_rows(t):
+    a = t.cpu().numpy()
+    n = int(a[-1, 0])
+    return np.ascontiguousarray(a[:n]).view(ROW_DTYPE).reshape(n)
+
+
+def gather_rows(local_rows, dist, torch, device):
+    """One padded gather of every rank's rows to rank 0.  Returns the concatenated rows sorted by
+    (contig, start, end) on rank 0, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cap = torch.tensor([len(local_rows)], dtype=torch.int64, device=device)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    capacity = int(cap.item())
+    send = rows_to_tensor(local_rows, capacity, torch, device)
+    recv = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)
+    if rank != 0:
+        return None
+    parts = [tensor_to_rows(t) for t in recv]
+    rows = np.concatenate(parts) if parts else np.zeros(0, dtype=ROW_DTYPE)
+    order = np.lexsort((rows["end"], rows["start"], rows["contig"]))
+    return rows[order]
+
+
+def scan_contigs_sharded(contigs, settings, scan_fn, dist, torch, device):
+    """contigs: list of bytes, identical on every rank.  scan_fn(list_of_bytes, settings) -> rows with
+    contig indices local to the list it was given.  Returns the rows of ALL contigs (global contig indices,
+    sorted) on rank 0, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = plan_contig_shards([len(c) for c in contigs], world)[rank]
+    if mine:
+        rows = np.array(scan_fn([contigs[i] for i in mine], settings), dtype=ROW_DTYPE)
+        if len(rows):
+            rows = rows.copy()
+            rows["contig"] = np.asarray(mine, dtype=np.uint32)[rows["contig"]]
+    else:
+        rows = np.zeros(0, dtype=ROW_DTYPE)
+    return gather_rows(rows, dist, torch, device)

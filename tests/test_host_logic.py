@@ -85,3 +85,43 @@ def test_min_repeats_one_is_refused_loudly(cpu_rows):
 
 def test_find_repeats_alias():
     assert prf.find_repeats is prf.detect_repeats
+
+
+# ---- command line (reference perfect_repeat_finder.py:83-183) ----
+
+def _write_fasta(path, gz=False):
+    import gzip
+    text = ">chrA first contig\n" + "ACGT" * 5 + "\n" + "CAG" * 8 + "\nTTGA\n" + ">chrB\n" + "gatc" + "a" * 12 + "CT\n"
+    (gzip.open(path, "wt") if gz else open(path, "wt")).write(text)
+    return {"chrA": "ACGT" * 5 + "CAG" * 8 + "TTGA", "chrB": "gatc" + "a" * 12 + "CT"}
+
+
+def test_cli_literal_sequence_writes_tsv(cpu_rows, tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    prf.main(["-min", "1", "-max", "6", "--min-repeats", "3", "--min-span", "9", "-o", "out", "ACGCAGCAGCAGCAGCAGTT"])
+    assert (tmp_path / "out.tsv").read_text() == "start_0based\tend\tmotif\n2\t18\tGCA\n"
+    assert "Found 1 repeats" in capsys.readouterr().out
+
+
+def test_cli_fasta_scans_every_contig_and_interval(cpu_rows, tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    for gz in (False, True):
+        fa = tmp_path / ("toy.fa.gz" if gz else "toy.fa")
+        seqs = _write_fasta(str(fa), gz)
+        prf.main([str(fa)])
+        want = ""
+        for name, seq in seqs.items():
+            fs = argparse.Namespace(min_motif_size=1, max_motif_size=50, min_repeats=3, min_span=9)
+            for s, e, k in closed_form_rows(seq, fs):
+                want += f"{name}\t{s}\t{e}\t{seq.upper()[s:s + k]}\n"
+        assert (tmp_path / "toy.bed").read_text() == want
+        assert want.count("\n") == 3
+    out = capsys.readouterr().out
+    assert "Processing chrA (48 bp)" in out and "Wrote results to toy.bed" in out
+    prf.main(["-i", "chrA:18-40", "-o", "iv", str(tmp_path / "toy.fa")])
+    from oracle import prf_oracle
+    fs = argparse.Namespace(min_motif_size=1, max_motif_size=50, min_repeats=3, min_span=9, interval_start_0based=18, interval_end=40)
+    want = "".join(f"chrA\t{s}\t{e}\t{m}\n" for s, e, m in prf_oracle.detect_repeats(seqs["chrA"], fs))
+    assert want and (tmp_path / "iv.bed").read_text() == want
+    with pytest.raises(SystemExit):
+        prf.main(["-i", "chrZ:1-5", str(tmp_path / "toy.fa")])

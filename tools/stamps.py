@@ -20,3 +20,9 @@ for w in range(4):
     print('wave', w, ' '.join(f'{n}={int(v)}' for n, v in zip(names, seg)), 'total', int(np.median(d[:, w, 6] - d[:, w, 0])))
 print('WG start spread (cycles): min', 0, 'median', int(np.median(d[:, 0, 0] - t0)), 'max', int((d[:, 0, 0] - t0).max()))
 print('WG end   (cycles): median', int(np.median(d[:, :, 6].max(axis=1) - t0)), 'max', int((d[:, :, 6].max(axis=1) - t0).max()))
+tot = (d[:, :, 6].max(axis=1) - d[:, :, 0].min(axis=1))
+print('WG total cycles: p50', int(np.percentile(tot, 50)), 'p90', int(np.percentile(tot, 90)), 'p99', int(np.percentile(tot, 99)), 'max', int(tot.max()), 'argmax', int(tot.argmax()), 'of', len(tot))
+print('last 4 WGs (mixed tiles are last):', tot[-4:])
+order = np.argsort(tot)[-6:]
+for i in order:
+    print('slow WG', int(i), 'total', int(tot[i]), 'phases w0', [int(d[i, 0, j + 1] - d[i, 0, j]) for j in range(6)])
