@@ -41,8 +41,9 @@ struct prf_vscan_args {
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
     const u32 *tile_list;          // clean tiles first, then mixed
     u32 n_clean, n_mixed;
-    prf_hit_dev *hit_slabs;        // [tile][hit_cap]
-    u32 *hit_counts;               // [tile]
+    u32 split;                     // workgroups per tile: 1, 2 or 4 (each takes 4/split of the 8-row blocks)
+    prf_hit_dev *hit_slabs;        // [tile*split + part][hit_cap]
+    u32 *hit_counts;               // [tile*split + part]
     u32 hit_cap;
     u32 min_repeats, min_span;
     const u64 *contig_base;

@@ -206,27 +206,40 @@ __device__ __forceinline__ void unpack4(u32 *dst, const uint4 v) {
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
 }
 
-// ---- group task: motif sizes k0 .. k0+7 (those in `valid`), all four 8-row blocks of the stream ----
-template <bool HASX>
-__device__ __forceinline__ void group_task(const uint4 *vimg, int nc, int lane, u32 k0, u32 valid, Emit &em) {
+// LDS image addressing.  The image is [plane][row group][virtual lane] of 16-byte slots, NC virtual lanes wide
+// (compile-time, so plane and row-group strides are instruction immediates).  Row group gg of a lane's
+// *extended* stream (gg >= 8: the stream continues in the next virtual lane) is slot (gg & 7) * NC + (gg >> 3)
+// from the lane's own slot.
+template <int NC>
+__device__ __forceinline__ const uint4 *slot_of(const uint4 *lane_base, int gg) {
+    return lane_base + ((gg & 7) * NC + (gg >> 3));
+}
+
+// ---- group task: motif sizes k0 .. k0+7 (those in `valid`), the 8-row blocks tb0 .. tb1-1 of the stream ----
+template <bool HASX, int NC>
+__device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, u32 valid, int tb0, int tb1, Emit &em) {
     constexpr int NP = HASX ? 3 : 2;
+    constexpr int PS = RG * NC;  // slots per plane
+    const uint4 *lane_base = vimg + lane;
     u32 prev[8];
     static_for<0, 8>([&](auto ic) { prev[decltype(ic)::value] = ~0u; });  // first group of a stream: report, verify decides
 #pragma unroll 1
-    for (int tb = 0; tb < 4; tb++) {
+    for (int tb = tb0; tb < tb1; tb++) {
         u32 a[3][8];   // rows 8tb .. 8tb+7
         u32 w[3][16];  // rows 8tb+k0 .. 8tb+k0+15 (k0 % 4 == 0: whole 16-byte slots)
-        const int g0 = 2 * tb + (int)(k0 >> 2);
+        const uint4 *pa = lane_base + 2 * tb * NC;
         static_for<0, NP>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
-            static_for<0, 2>([&](auto hc) {
-                constexpr int h = decltype(hc)::value;
-                unpack4(&a[p][4 * h], vimg[(p * RG + 2 * tb + h) * nc + lane]);
-            });
-            static_for<0, 4>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                const int gg = g0 + g;
-                unpack4(&w[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+            unpack4(&a[p][0], pa[p * PS]);
+            unpack4(&a[p][4], pa[p * PS + NC]);
+        });
+        const int g0 = 2 * tb + (int)(k0 >> 2);
+        static_for<0, 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const uint4 *pw = slot_of<NC>(lane_base, g0 + g);
+            static_for<0, NP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                unpack4(&w[p][4 * g], pw[p * PS]);
             });
         });
         u32 cand[8];
@@ -274,29 +287,34 @@ __device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO
 }
 
 // ---- exact task: one motif size k whose minimum run length is M < 15; O = k % 4 ----
-template <int M, int O, bool HASX>
-__device__ __forceinline__ void exact_task(const uint4 *vimg, int nc, int lane, u32 k, Emit &em) {
+template <int M, int O, bool HASX, int NC>
+__device__ __forceinline__ void exact_task(const uint4 *vimg, int lane, u32 k, int tb0, int tb1, Emit &em) {
     constexpr int NP = HASX ? 3 : 2;
+    constexpr int PS = RG * NC;
     constexpr int NR = 8 + M - 1;          // mismatch words needed per block: rows t0 .. t0+NR-1
     constexpr int NGB = (NR + 3) / 4;      // 16-byte slots of base rows
     constexpr int NGS = (O + NR + 3) / 4;  // 16-byte slots of the rows shifted by k (first one starts O rows early)
-    u32 mprev = ~0u;  // mismatch word of the row before the block; unknown at row 0 -> report, verify decides
+    const uint4 *lane_base = vimg + lane;
+    u32 mprev = ~0u;  // mismatch word of the row before the block; unknown at the first block -> report, verify decides
 #pragma unroll 1
-    for (int tb = 0; tb < 4; tb++) {
+    for (int tb = tb0; tb < tb1; tb++) {
         u32 a[3][4 * NGB];
         u32 s[3][4 * NGS];
         const int gs0 = 2 * tb + (int)(k >> 2);
-        static_for<0, NP>([&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            static_for<0, NGB>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                const int gg = 2 * tb + g;
-                unpack4(&a[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+        static_for<0, NGB>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const uint4 *pb = slot_of<NC>(lane_base, 2 * tb + g);
+            static_for<0, NP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                unpack4(&a[p][4 * g], pb[p * PS]);
             });
-            static_for<0, NGS>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                const int gg = gs0 + g;
-                unpack4(&s[p][4 * g], vimg[(p * RG + (gg & 7)) * nc + lane + (gg >> 3)]);
+        });
+        static_for<0, NGS>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const uint4 *pw = slot_of<NC>(lane_base, gs0 + g);
+            static_for<0, NP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                unpack4(&s[p][4 * g], pw[p * PS]);
             });
         });
         u32 m[NR + 1];
@@ -326,44 +344,44 @@ __device__ __forceinline__ void exact_task(const uint4 *vimg, int nc, int lane, 
     }
 }
 
-template <int M, bool HASX>
-__device__ __forceinline__ void exact_task_any(const uint4 *vimg, int nc, int lane, u32 k, Emit &em) {
+template <int M, bool HASX, int NC>
+__device__ __forceinline__ void exact_task_any(const uint4 *vimg, int lane, u32 k, int tb0, int tb1, Emit &em) {
     switch (k & 3u) {  // wave-uniform
-        case 0: exact_task<M, 0, HASX>(vimg, nc, lane, k, em); break;
-        case 1: exact_task<M, 1, HASX>(vimg, nc, lane, k, em); break;
-        case 2: exact_task<M, 2, HASX>(vimg, nc, lane, k, em); break;
-        default: exact_task<M, 3, HASX>(vimg, nc, lane, k, em); break;
+        case 0: exact_task<M, 0, HASX, NC>(vimg, lane, k, tb0, tb1, em); break;
+        case 1: exact_task<M, 1, HASX, NC>(vimg, lane, k, tb0, tb1, em); break;
+        case 2: exact_task<M, 2, HASX, NC>(vimg, lane, k, tb0, tb1, em); break;
+        default: exact_task<M, 3, HASX, NC>(vimg, lane, k, tb0, tb1, em); break;
     }
 }
 
-template <bool HASX>
-__device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &plan, int wave, int lane, Emit &em) {
+template <bool HASX, int NC>
+__device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &plan, int wave, int lane, int tb0, int tb1, Emit &em) {
     const u32 t_end = plan.wave_begin[wave + 1];
-    const int nc = (int)plan.nc;
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
         const prf_vtask task = plan.tasks[ti];
         switch (task.kind) {
-            case 0: group_task<HASX>(vimg, nc, lane, task.k0, task.valid, em); break;
-            case 1: exact_task_any<1, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 2: exact_task_any<2, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 3: exact_task_any<3, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 4: exact_task_any<4, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 5: exact_task_any<5, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 6: exact_task_any<6, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 7: exact_task_any<7, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 8: exact_task_any<8, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 9: exact_task_any<9, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 10: exact_task_any<10, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 11: exact_task_any<11, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 12: exact_task_any<12, HASX>(vimg, nc, lane, task.k0, em); break;
-            case 13: exact_task_any<13, HASX>(vimg, nc, lane, task.k0, em); break;
-            default: exact_task_any<14, HASX>(vimg, nc, lane, task.k0, em); break;
+            case 0: group_task<HASX, NC>(vimg, lane, task.k0, task.valid, tb0, tb1, em); break;
+            case 1: exact_task_any<1, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 2: exact_task_any<2, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 3: exact_task_any<3, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 4: exact_task_any<4, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 5: exact_task_any<5, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 6: exact_task_any<6, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 7: exact_task_any<7, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 8: exact_task_any<8, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 9: exact_task_any<9, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 10: exact_task_any<10, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 11: exact_task_any<11, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 12: exact_task_any<12, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            case 13: exact_task_any<13, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
+            default: exact_task_any<14, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
         }
     }
 }
 
+template <int NC>
 __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_args g) {
-    const int nc = (int)g.plan.nc;
+    constexpr int nc = NC;
     uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem + SMEM_HDR);
     const u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)3 * RG * nc * sizeof(uint4));
     u64 *lin = reinterpret_cast<u64 *>(prf_smem + lin_off);
@@ -373,8 +391,12 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
 
     const int nt = (int)blockDim.x;
     const int tid = (int)threadIdx.x;
-    const u64 tile = g.tile_list[blockIdx.x];
-    const bool hasx = blockIdx.x >= g.n_clean;  // the list holds the clean tiles first
+    // `split` workgroups share a tile, each taking 4/split of the 8-row blocks (small inputs: more, shorter workgroups)
+    const u32 split = g.split;
+    const u32 list_idx = blockIdx.x / split, part = blockIdx.x % split;
+    const int tb0 = (int)(part * (4u / split)), tb1 = tb0 + (int)(4u / split);
+    const u64 tile = g.tile_list[list_idx];
+    const bool hasx = list_idx >= g.n_clean;  // the list holds the clean tiles first
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int extra = nc - 64;
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             tc.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
             tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
             tc.H = g.H; tc.L = g.L; tc.X = g.X;
-            tc.slab = g.hit_slabs + tile * (u64)g.hit_cap;
+            tc.slab = g.hit_slabs + (tile * split + part) * (u64)g.hit_cap;
             // contigs start on tile boundaries, so every run that this tile reports lies in the tile's contig
             tc.contig = prf_contig_of(g.contig_base, g.n_contigs, tile * PRF_TILE);
             tc.contig_base = g.contig_base[tc.contig];
@@ -438,8 +460,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     em.handled = 0;
     em.lane_pos = tile * PRF_TILE + (u64)lane * T;
     em.lane = lane;
-    if (hasx) run_tasks<true>(vimg, g.plan, wave, lane, em);
-    else run_tasks<false>(vimg, g.plan, wave, lane, em);
+    if (hasx) run_tasks<true, NC>(vimg, g.plan, wave, lane, tb0, tb1, em);
+    else run_tasks<false, NC>(vimg, g.plan, wave, lane, tb0, tb1, em);
     if (lane == 0) rec_cnt[wave] = em.cnt;  // waves the plan does not use keep the 0 from staging
     PRF_STAMP(3);
     __syncthreads();
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
     if (tid == 0) {
         const u32 n = *hit_cnt;
-        g.hit_counts[tile] = n < g.hit_cap ? n : g.hit_cap;
+        g.hit_counts[tile * split + part] = n < g.hit_cap ? n : g.hit_cap;
         atomicAdd(&sh[PRF_SH_HITS], (u64)n);
         if (n > g.hit_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
     }
@@ -585,7 +607,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.valid = 1;
             it.cost = 40 + (u32)(8 + M - 1) * 12;  // per block: single-dword reads of the shifted rows + ~5 VALU per row
             items.push_back(it);
-            reach = std::max<u32>(reach, k + 7 + (u32)M - 1);
+            const u32 nr = 8 + (u32)M - 1;  // rows per block; whole 16-byte slots are read
+            reach = std::max<u32>(reach, (k & ~3u) + 4 * (((k & 3u) + nr + 3) / 4) - 1);
         } else if (k >= covered_to) {
             const u32 k0 = k & ~3u;
             u32 valid = 0;
@@ -624,7 +647,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
         for (const Item &it : bins[w]) plan->tasks[plan->n_tasks++] = it.t;
     }
     for (u32 w = nw; w <= PRF_VMAX_WAVES; w++) plan->wave_begin[w] = plan->n_tasks;
-    plan->nc = 64 + (T - 1 + reach) / T + 1;
+    const u32 need_nc = 64 + (24 + reach) / T;  // the last block starts at row 24; virtual lanes 64 .. 63+offset
+    plan->nc = need_nc <= 66 ? 66 : (need_nc <= 72 ? 72 : 80);  // the widths the kernel is instantiated for
     plan->lds_bytes = (u32)(SMEM_HDR + (size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
                             (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64));
     return true;
@@ -633,7 +657,13 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
     const u32 n = args.n_clean + args.n_mixed;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(prf_vscan_kernel, dim3(n), dim3(64 * args.plan.n_waves), args.plan.lds_bytes, s, args);
+    const dim3 grid(n * args.split), block(64 * args.plan.n_waves);
+    switch (args.plan.nc) {
+        case 66: hipLaunchKernelGGL(prf_vscan_kernel<66>, grid, block, args.plan.lds_bytes, s, args); break;
+        case 72: hipLaunchKernelGGL(prf_vscan_kernel<72>, grid, block, args.plan.lds_bytes, s, args); break;
+        case 80: hipLaunchKernelGGL(prf_vscan_kernel<80>, grid, block, args.plan.lds_bytes, s, args); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
