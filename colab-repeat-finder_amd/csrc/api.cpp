@@ -337,14 +337,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         bool again = false;
         if (vs) {
             // ---- fused bit-sliced kernel: scan + verify + rows in one launch ----
-            // small inputs: split every tile over 2 or 4 workgroups so that the chip is filled and a
-            // workgroup is short (the kernel's time is the slowest workgroup's when there is one round)
-            u32 split = 1;  // measured on chr22 (616 tiles): 1 -> 52.8 us, 2 -> 67.7 us, 4 -> 92.4 us: throughput-, not latency-bound
-            if (const char *e = getenv("PRF_SPLIT")) {  // tuning aid
-                const int v = atoi(e);
-                if (v == 1 || v == 2 || v == 4) split = (u32)v;
-            }
-            const u64 nslabs = ntiles * 4;  // sized for any split
+            const u64 nslabs = ntiles * 4;  // a tile with N in reach is scanned by 4 workgroups, each with its own slab
             int rc = ensure_slabs(c, nslabs, slab_cap, g->serial);
             if (rc) return rc;
             prf_vscan_args &a = va;
@@ -352,7 +345,6 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.H = g->H; a.L = g->L; a.X = g->X;
             a.tile_list = g->vp.tile_list;
             a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
-            a.split = split;
             a.hit_slabs = c->d_hit_slabs; a.hit_counts = c->d_hit_counts; a.hit_cap = c->slab_cap;
             a.min_repeats = min_repeats; a.min_span = min_span;
             a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
@@ -393,7 +385,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
             if (!again) {
                 c->last_in_slabs = true;
-                c->last_ntiles = ntiles * split;
+                c->last_ntiles = nslabs;
             }
         } else {
             // ---- generic path: candidates, then rows ----

@@ -41,9 +41,8 @@ struct prf_vscan_args {
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
     const u32 *tile_list;          // clean tiles first, then mixed
     u32 n_clean, n_mixed;
-    u32 split;                     // workgroups per tile: 1, 2 or 4 (each takes 4/split of the 8-row blocks)
-    prf_hit_dev *hit_slabs;        // [tile*split + part][hit_cap]
-    u32 *hit_counts;               // [tile*split + part]
+    prf_hit_dev *hit_slabs;        // [tile*4 + part][hit_cap]  (clean tiles use part 0 only)
+    u32 *hit_counts;               // [tile*4 + part]
     u32 hit_cap;
     u32 min_repeats, min_span;
     const u64 *contig_base;

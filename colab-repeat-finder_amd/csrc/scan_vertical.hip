@@ -60,7 +60,7 @@ constexpr int RG = T / 4;  // row groups of 4 rows = one 16-byte slot per lane
 constexpr int LIN_PRE = 1;                                    // linear window: words before the tile
 constexpr int LIN_POST = 24;                                  // ... and after it
 constexpr int LW = (int)PRF_TILE_WORDS + LIN_PRE + LIN_POST;  // words per plane in the LDS window
-constexpr int REC_PER_WAVE = 256;                             // candidate records per wave (LDS list)
+constexpr int REC_PER_WAVE = 128;                             // candidate records per wave (LDS list)
 constexpr int MAX_WAVES = 4;
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
 
@@ -94,6 +94,7 @@ struct TileCtx {
     u32 hit_cap;
     u32 min_repeats, min_span;
     u32 lin_off;              // byte offset of the linear window in LDS
+    u32 x_in_lds;             // the window holds X too
 };
 static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 
@@ -112,6 +113,7 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
     view.nwords = LW;
     view.xz_lo = tc.xz_lo;
     view.xz_hi = tc.xz_hi;
+    view.x_in_lds = tc.x_in_lds;
     view.P[0] = tc.H; view.P[1] = tc.L; view.P[2] = tc.X;
     const u32 min_repeats = tc.min_repeats, min_span = tc.min_span, hit_cap = tc.hit_cap, contig = tc.contig;
     const u64 contig_base = tc.contig_base;
@@ -379,6 +381,8 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &pl
     }
 }
 
+// Grid: first 4 workgroups per tile with N in reach (the 3-plane variant is slower, so each takes one of the
+// four 8-row blocks and they start first), then one workgroup per clean tile.
 template <int NC>
 __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr int nc = NC;
@@ -391,12 +395,11 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
 
     const int nt = (int)blockDim.x;
     const int tid = (int)threadIdx.x;
-    // `split` workgroups share a tile, each taking 4/split of the 8-row blocks (small inputs: more, shorter workgroups)
-    const u32 split = g.split;
-    const u32 list_idx = blockIdx.x / split, part = blockIdx.x % split;
-    const int tb0 = (int)(part * (4u / split)), tb1 = tb0 + (int)(4u / split);
-    const u64 tile = g.tile_list[list_idx];
-    const bool hasx = list_idx >= g.n_clean;  // the list holds the clean tiles first
+    const bool hasx = blockIdx.x < 4u * g.n_mixed;
+    const u32 part = hasx ? (blockIdx.x & 3u) : 0u;
+    const int tb0 = hasx ? (int)part : 0, tb1 = hasx ? (int)part + 1 : 4;
+    // the list holds the clean tiles first, then the mixed ones
+    const u64 tile = g.tile_list[hasx ? g.n_clean + (blockIdx.x >> 2) : blockIdx.x - 4u * g.n_mixed];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int extra = nc - 64;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             tc.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
             tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
             tc.H = g.H; tc.L = g.L; tc.X = g.X;
-            tc.slab = g.hit_slabs + (tile * split + part) * (u64)g.hit_cap;
+            tc.slab = g.hit_slabs + (tile * 4 + part) * (u64)g.hit_cap;
             // contigs start on tile boundaries, so every run that this tile reports lies in the tile's contig
             tc.contig = prf_contig_of(g.contig_base, g.n_contigs, tile * PRF_TILE);
             tc.contig_base = g.contig_base[tc.contig];
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             tc.min_repeats = g.min_repeats;
             tc.min_span = g.min_span;
             tc.lin_off = lin_off;
+            tc.x_in_lds = 0u;
             *reinterpret_cast<TileCtx *>(prf_smem) = tc;
         }
     }
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
     if (tid == 0) {
         const u32 n = *hit_cnt;
-        g.hit_counts[tile * split + part] = n < g.hit_cap ? n : g.hit_cap;
+        g.hit_counts[tile * 4 + part] = n < g.hit_cap ? n : g.hit_cap;
         atomicAdd(&sh[PRF_SH_HITS], (u64)n);
         if (n > g.hit_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
     }
@@ -655,9 +659,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
 }
 
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
-    const u32 n = args.n_clean + args.n_mixed;
+    const u32 n = args.n_clean + 4u * args.n_mixed;
     if (n == 0) return hipSuccess;
-    const dim3 grid(n * args.split), block(64 * args.plan.n_waves);
+    const dim3 grid(n), block(64 * args.plan.n_waves);
     switch (args.plan.nc) {
         case 66: hipLaunchKernelGGL(prf_vscan_kernel<66>, grid, block, args.plan.lds_bytes, s, args); break;
         case 72: hipLaunchKernelGGL(prf_vscan_kernel<72>, grid, block, args.plan.lds_bytes, s, args); break;

@@ -26,19 +26,20 @@ struct prf_global_view {
     }
 };
 
-// a window of the H and L linear planes staged in LDS ([plane][nwords], first word = global word w0);
-// positions outside the window fall through to global memory.  The not-ACGT plane X is not staged: it
-// is known to be zero on [xz_lo, xz_hi) (a clean tile and its successor) and read from global memory
-// elsewhere (the 64 positions in front of the tile; tiles with N in them).
+// a window of the linear planes staged in LDS ([plane][nwords], first word = global word w0); positions
+// outside the window fall through to global memory.  For clean tiles only H and L are staged: the
+// not-ACGT plane X is known to be zero on [xz_lo, xz_hi) (the tile and its successor) and read from global
+// memory elsewhere (the 64 positions in front of the tile).  Tiles with N in reach stage X as well.
 typedef __attribute__((address_space(3))) const u64 prf_lds_cu64;  // explicitly LDS: ds_read, not flat_load
 struct prf_window_view {
     prf_lds_cu64 *lds;
     u64 w0;
     u32 nwords;
     u64 xz_lo, xz_hi;
+    u32 x_in_lds;  // 1: the window also holds the X plane (third), used by tiles with N in reach
     const u64 *P[3];
     __device__ __forceinline__ u64 bits(int plane, u64 q) const {
-        if (plane == 2) {
+        if (plane == 2 && !x_in_lds) {
             if (q >= xz_lo && q + 64 <= xz_hi) return 0;
             return prf_bits_at(P[2], q);
         }
