@@ -244,29 +244,29 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, 
                 unpack4(&w[p][4 * g], pw[p * PS]);
             });
         });
+        // All 8 motif sizes are computed in one straight-line block so that their 8 independent OR chains
+        // interleave (a chain alone is 16 dependent operations); sizes outside `valid` are masked at the end.
         u32 cand[8];
         u32 hot = 0;
         static_for<0, 8>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
-            u32 c = 0;
-            if ((valid >> kk) & 1u) {  // wave-uniform
-                // OR over the 8 rows of (H^H')|(L^L'): 16 operations, no per-row mismatch word
-                u32 o = a[0][0] ^ w[0][kk];
-                o = or_xor(o, a[1][0], w[1][kk]);
-                static_for<1, 8>([&](auto ic) {
+            // OR over the 8 rows of (H^H')|(L^L'): 16 operations, no per-row mismatch word
+            u32 o = a[0][0] ^ w[0][kk];
+            o = or_xor(o, a[1][0], w[1][kk]);
+            static_for<1, 8>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                o = or_xor(o, a[0][i], w[0][kk + i]);
+                o = or_xor(o, a[1][i], w[1][kk + i]);
+            });
+            if constexpr (HASX) {
+                static_for<0, 8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    o = or_xor(o, a[0][i], w[0][kk + i]);
-                    o = or_xor(o, a[1][i], w[1][kk + i]);
+                    o = o | a[2][i] | w[2][kk + i];
                 });
-                if constexpr (HASX) {
-                    static_for<0, 8>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        o = o | a[2][i] | w[2][kk + i];
-                    });
-                }
-                c = ~o & prev[kk];  // all 8 rows match, the previous group did not (or is unknown)
-                prev[kk] = o;
             }
+            const u32 vm = ((valid >> kk) & 1u) ? ~0u : 0u;  // wave-uniform
+            const u32 c = ~o & prev[kk] & vm;  // all 8 rows match, the previous group did not (or is unknown)
+            prev[kk] = o;
             cand[kk] = c;
             hot |= c;
         });
