@@ -27,6 +27,8 @@ typedef unsigned int u32;
 #define PRF_KIND_START 0ull   // pos is the exact first matching position of a maximal run
 #define PRF_KIND_GROUP 1ull   // pos is the first position of an aligned all-match group of 8; the run
                               // may have begun up to 7 (leader) or more (not a leader) positions earlier
+#define PRF_KIND_GROUP2 2ull  // the same, but only every 2nd aligned group is examined (M(k) >= 23) ...
+#define PRF_KIND_GROUP4 3ull  // ... every 4th (M(k) >= 39): "leader" = first EXAMINED all-match group of the run
 
 struct prf_hit_dev {
     u64 start, end;

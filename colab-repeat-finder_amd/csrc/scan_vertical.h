@@ -4,7 +4,7 @@
 #include "prf_device.h"
 
 #define PRF_VMAX_K 480       // largest motif size the fused kernel takes (9-bit k field, LDS image width)
-#define PRF_VMAX_TASKS 96
+#define PRF_VMAX_TASKS 80
 #define PRF_VMAX_WAVES 16
 
 // Bit-sliced planes: see scan_vertical.hip for the layout.
@@ -23,6 +23,8 @@ struct prf_vtask {
     unsigned short k0;
     unsigned char kind;
     unsigned char valid;
+    unsigned char stride;   // group tasks: examine every `stride`-th aligned group of 8 rows (1, 2 or 4)
+    unsigned char pad[3];
 };
 
 // Work plan of one scan (host-built from kmin,kmax,min_repeats,min_span): tasks grouped per wave.

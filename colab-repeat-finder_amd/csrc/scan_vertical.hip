@@ -74,9 +74,9 @@ __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B > A) static_for_impl<A>(static_cast<F &&>(f), std::make_integer_sequence<int, B - A>{});
 }
 
-// ---- candidate records: [36:0] position/8, [37] kind, [46:38] k (START) or k0 (GROUP), [54:47] mask ----
+// ---- candidate records: [36:0] position/8, [38:37] kind, [47:39] k (START) or k0 (GROUP*), [55:48] mask ----
 __device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
-    return (pos >> 3) | (kind << 37) | ((u64)k << 38) | ((u64)mask << 47);
+    return (pos >> 3) | (kind << 37) | ((u64)k << 39) | ((u64)mask << 48);
 }
 
 // dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
@@ -132,14 +132,14 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
         else slot_idx = 3 * REC_PER_WAVE + (idx - c2);
         const u64 rec = recs[slot_idx];
         const u64 p8 = (rec & ((1ull << 37) - 1ull)) << 3;
-        const u32 kind = (u32)(rec >> 37) & 1u;
-        const u32 kk = (u32)(rec >> 38) & 511u;
-        u32 mask = (u32)(rec >> 47) & 255u;
+        const u32 kind = (u32)(rec >> 37) & 3u;
+        const u32 kk = (u32)(rec >> 39) & 511u;
+        u32 mask = (u32)(rec >> 48) & 255u;
         while (mask) {
             const u32 bit = (u32)__builtin_ctz(mask);
             mask &= mask - 1;
-            const u64 p = kind == (u32)PRF_KIND_GROUP ? p8 : p8 + bit;
-            const u32 k = kind == (u32)PRF_KIND_GROUP ? kk + bit : kk;
+            const u64 p = kind == (u32)PRF_KIND_START ? p8 + bit : p8;  // START: the mask selects rows, else motif sizes
+            const u32 k = kind == (u32)PRF_KIND_START ? kk : kk + bit;
             u64 a, b;
             if (prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b)) {
                 const u32 slot = atomicAdd(hit_cnt, 1u);
@@ -219,14 +219,19 @@ __device__ __forceinline__ const uint4 *slot_of(const uint4 *lane_base, int gg) 
 
 // ---- group task: motif sizes k0 .. k0+7 (those in `valid`), the 8-row blocks tb0 .. tb1-1 of the stream ----
 template <bool HASX, int NC>
-__device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, u32 valid, int tb0, int tb1, Emit &em) {
+__device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, u32 valid, u32 stride, int tb0, int tb1, Emit &em) {
     constexpr int NP = HASX ? 3 : 2;
     constexpr int PS = RG * NC;  // slots per plane
     const uint4 *lane_base = vimg + lane;
     u32 prev[8];
     static_for<0, 8>([&](auto ic) { prev[decltype(ic)::value] = ~0u; });  // first group of a stream: report, verify decides
+    // stride 2 / 4: all motif sizes of the chunk have M(k) >= 23 / 39, and a run that long contains an aligned
+    // all-match group whose index is a multiple of 2 / 4, so only those blocks are examined.  The group before
+    // an examined one is then unknown: every examined all-match group reports, verify keeps the first of a run.
+    const u64 kind = stride == 1 ? PRF_KIND_GROUP : (stride == 2 ? PRF_KIND_GROUP2 : PRF_KIND_GROUP4);
 #pragma unroll 1
     for (int tb = tb0; tb < tb1; tb++) {
+        if (tb & (int)(stride - 1)) continue;
         u32 a[3][8];   // rows 8tb .. 8tb+7
         u32 w[3][16];  // rows 8tb+k0 .. 8tb+k0+15 (k0 % 4 == 0: whole 16-byte slots)
         const uint4 *pa = lane_base + 2 * tb * NC;
@@ -266,11 +271,11 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, 
             }
             const u32 vm = ((valid >> kk) & 1u) ? ~0u : 0u;  // wave-uniform
             const u32 c = ~o & prev[kk] & vm;  // all 8 rows match, the previous group did not (or is unknown)
-            prev[kk] = o;
+            prev[kk] = stride == 1 ? o : ~0u;
             cand[kk] = c;
             hot |= c;
         });
-        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, PRF_KIND_GROUP, k0);
+        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, kind, k0);
     }
 }
 
@@ -362,7 +367,7 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &pl
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
         const prf_vtask task = plan.tasks[ti];
         switch (task.kind) {
-            case 0: group_task<HASX, NC>(vimg, lane, task.k0, task.valid, tb0, tb1, em); break;
+            case 0: group_task<HASX, NC>(vimg, lane, task.k0, task.valid, task.stride, tb0, tb1, em); break;
             case 1: exact_task_any<1, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
             case 2: exact_task_any<2, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
             case 3: exact_task_any<3, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
@@ -609,6 +614,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.k0 = (unsigned short)k;
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
+            it.t.stride = 1;
             it.cost = 40 + (u32)(8 + M - 1) * 12;  // per block: single-dword reads of the shifted rows + ~5 VALU per row
             items.push_back(it);
             const u32 nr = 8 + (u32)M - 1;  // rows per block; whole 16-byte slots are read
@@ -620,11 +626,18 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
                 const u32 kx = k0 + kk;
                 if (kx >= kmin && kx <= kmax && prf_min_matches(kx, min_repeats, min_span) >= SMALL_M) valid |= 1u << kk;
             }
+            // examine every group, every 2nd or every 4th: a run of >= 8*S + 7 positions contains an aligned group
+            // of 8 whose index is a multiple of S
+            long long mmin = 1ll << 40;
+            for (u32 kk = 0; kk < 8; kk++)
+                if ((valid >> kk) & 1u) mmin = std::min(mmin, prf_min_matches(k0 + kk, min_repeats, min_span));
+            const u32 stride = mmin >= 39 ? 4u : (mmin >= 23 ? 2u : 1u);
             Item it;
             it.t.k0 = (unsigned short)k0;
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
-            it.cost = 40 + 20 * (u32)__builtin_popcount(valid);
+            it.t.stride = (unsigned char)stride;
+            it.cost = (40 + 20 * (u32)__builtin_popcount(valid)) / stride + 10;
             items.push_back(it);
             reach = std::max<u32>(reach, k0 + 15);
             covered_to = k0 + 8;

@@ -119,32 +119,43 @@ __device__ __forceinline__ bool prf_vmotif_is_repeat(const View &v, u64 a, u32 k
 }
 
 // One candidate (p, k, kind) -> true and the run [a, b) if it is a row.
-//  kind GROUP: [p, p+8) all match; the run is reported only by its first aligned all-match group.
+//  kind GROUP/GROUP2/GROUP4: [p, p+8) all match; the run is reported only by the first of its examined
+//              aligned all-match groups (every 1st / 2nd / 4th aligned group of 8 is examined).
 //  kind START: p is expected to be the first matching position of the run (a conservatively reported p
 //              that sits inside a run is dropped: the real start reports it).
 template <class View>
 __device__ __forceinline__ bool prf_candidate_to_run(const View &v, u64 p, u32 k, u32 kind, u32 min_repeats, u32 min_span,
                                                      u64 &a_out, u64 &b_out) {
-    // one 64-position look from just before the candidate usually shows the whole run
-    const u32 back = kind == (u32)PRF_KIND_GROUP ? 8u : 1u;
+    // One 64-position look from just before the candidate usually shows the whole run.
+    // `back`: how far before p the previous examined position/group lies (1 for START; 8, 16, 32 for groups
+    // examined at every 1st, 2nd, 4th aligned group of 8).
+    const u32 back = kind == (u32)PRF_KIND_START ? 1u : (8u << (kind - 1u));
+    const u32 look = p >= back ? back : (u32)p;  // the contig / array starts less than `back` before p
     u64 a = p, b;
-    u64 mm;
-    if (p >= back) {
-        mm = prf_vmismatch64(v, p - back, k);
-        if (kind == (u32)PRF_KIND_GROUP) {
-            const u64 lead = mm & 0xFFull;
-            if (lead == 0) return false;               // an earlier group is the leader
-            a = p - (u64)__builtin_clzll(lead << 56);  // matches directly before p
-        } else {
-            if ((mm & 1ull) == 0) return false;        // p sits inside a run: its real start reports it
+    u64 mm = ~0ull;
+    if (look) {
+        mm = prf_vmismatch64(v, p - look, k);
+        const u64 lead = mm & ((1ull << look) - 1ull);
+        if (kind != (u32)PRF_KIND_START) {
+            if (lead == 0) {
+                if (look == back) return false;  // the previous examined group lies in the same run: it reports
+                a = p - look;                    // run starts at position 0
+            } else {
+                a = p - (u64)__builtin_clzll(lead << (64 - look));  // matches directly before p
+            }
+        } else if (lead == 0) {
+            return false;  // p sits inside a run: its real start reports it
         }
-        mm >>= back;  // bit i = mismatch at p+i, for i < 64-back
-        mm |= ~0ull << (64 - back);
-        if (mm != (~0ull << (64 - back))) {
-            b = p + (u64)__builtin_ctzll(mm);
+        mm >>= look;  // bit i = mismatch at p+i, for i < 64-look
+    }
+    {
+        const u32 known = 64 - look;  // valid low bits of mm (0 when look == 0 ... then mm is all ones: unknown)
+        const u64 seen = look ? (mm & ((known < 64) ? ((1ull << known) - 1ull) : ~0ull)) : 0ull;
+        if (look && seen) {
+            b = p + (u64)__builtin_ctzll(seen);
         } else {
-            b = p + (64 - back);
-            for (;;) {  // long run: keep walking (the guard gap guarantees an end)
+            b = look ? p + known : p;
+            for (;;) {  // long run (or nothing seen yet): keep walking; the guard gap guarantees an end
                 const u64 m2 = prf_vmismatch64(v, b, k);
                 if (m2) {
                     b += (u64)__builtin_ctzll(m2);
@@ -152,16 +163,6 @@ __device__ __forceinline__ bool prf_candidate_to_run(const View &v, u64 p, u32 k
                 }
                 b += 64;
             }
-        }
-    } else {
-        b = p;
-        for (;;) {
-            const u64 m2 = prf_vmismatch64(v, b, k);
-            if (m2) {
-                b += (u64)__builtin_ctzll(m2);
-                break;
-            }
-            b += 64;
         }
     }
     if ((long long)(b - a) < prf_min_matches(k, min_repeats, min_span)) return false;
