@@ -101,6 +101,79 @@ static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 __device__ __forceinline__ u32 *smem_rec_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128); }
 __device__ __forceinline__ u32 *smem_hit_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128 + 4 * MAX_WAVES); }
 
+// ---- lean verification for the common case: a candidate well inside a clean tile ----
+// All looks are 32 positions wide and read the LDS window only (H and L; the not-ACGT plane is known to be
+// zero there).  Positions are window-relative bit offsets (bit 0 = 64 positions before the tile).
+typedef __attribute__((address_space(3))) const u32 prf_lds_cu32;
+
+__device__ __forceinline__ u32 look32(prf_lds_cu32 *plane, u32 q) {
+    const u32 w = q >> 5;
+    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], q & 31u);
+}
+// mismatch bits of window positions q .. q+31 against q+k ..
+__device__ __forceinline__ u32 mismatch32(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 q, u32 k) {
+    return (look32(h, q) ^ look32(h, q + k)) | (look32(l, q) ^ look32(l, q + k));
+}
+// does the word at window positions [a, a+k) have period d?  (k - d positions to compare)
+__device__ __forceinline__ bool has_period32(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 a, u32 k, u32 d) {
+    const u32 need = k - d;
+    for (u32 off = 0; off < need; off += 32) {
+        u32 mm = mismatch32(h, l, a + off, d);
+        const u32 left = need - off;
+        if (left < 32) mm &= (1u << left) - 1u;
+        if (mm) return false;
+    }
+    return true;
+}
+// 0: not a row; 1: row, run [a, b) in window positions; 2: outside the fast path's reach -> generic routine
+__device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 p, u32 k, u32 kind, u32 min_repeats,
+                                              u32 min_span, u32 lo_ok, u32 hi_ok, u32 &a_out, u32 &b_out) {
+    if (p < lo_ok + 32u || p + k + 64u > hi_ok) return 2;
+    const u32 back = kind == (u32)PRF_KIND_START ? 1u : (8u << (kind - 1u));  // 1, 8, 16, 32
+    const u32 before = mismatch32(h, l, p - 32u, k);  // bit 31 = position p-1
+    const u32 nmatch = (u32)__builtin_clz(before | 1u);   // matches directly before p (31 if none seen: >= back then)
+    if (before == 0 || nmatch >= back) return 0;         // START: p sits inside a run; GROUP*: an earlier examined group reports
+    const u32 a = p - nmatch;
+    u32 b = p;
+    for (;;) {
+        if (b + k + 64u > hi_ok) return 2;
+        const u32 mm = mismatch32(h, l, b, k);
+        if (mm) {
+            b += (u32)__builtin_ctz(mm);
+            break;
+        }
+        b += 32u;
+    }
+    if ((long long)(b - a) < prf_min_matches(k, min_repeats, min_span)) return 0;
+    // primitive motif: no period k/q for a prime q | k
+    u32 rest = k;
+#define PRF_TRY_PRIME32(P)                                   \
+    if (rest % P == 0) {                                     \
+        if (has_period32(h, l, a, k, k / P)) return 0;       \
+        do rest /= P; while (rest % P == 0);                 \
+    }
+    if (k >= 2) {
+        PRF_TRY_PRIME32(2u)
+        PRF_TRY_PRIME32(3u)
+        if (rest > 1) {
+            PRF_TRY_PRIME32(5u)
+            PRF_TRY_PRIME32(7u)
+            if (rest > 1) {
+                PRF_TRY_PRIME32(11u)
+                PRF_TRY_PRIME32(13u)
+                PRF_TRY_PRIME32(17u)
+                PRF_TRY_PRIME32(19u)
+                PRF_TRY_PRIME32(23u)
+                if (rest > 1 && has_period32(h, l, a, k, k / rest)) return 0;  // k <= 480 < 29*29: rest is prime
+            }
+        }
+    }
+#undef PRF_TRY_PRIME32
+    a_out = a;
+    b_out = b;
+    return 1;
+}
+
 // Candidate records -> rows.  only_list >= 0: the records [0, n) of that wave's list, taken by lanes
 // first, first+stride, ... (a wave emptying its own full list in the middle of the scan).  only_list < 0:
 // the records of all lists, as one index space [0, n) (the cooperative pass at the end of the tile).
@@ -119,6 +192,12 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
     const u64 contig_base = tc.contig_base;
     prf_hit_dev *slab = tc.slab;
     u32 *hit_cnt = smem_hit_cnt();
+    // fast path: window-relative positions; valid where the window is staged and holds no not-ACGT position
+    const u64 win_pos0 = tc.w0 * 64;
+    prf_lds_cu32 *fh = (prf_lds_cu32 *)(prf_smem + tc.lin_off);
+    prf_lds_cu32 *fl = fh + 2 * LW;
+    const u32 fast_lo = 64u;                                             // the tile starts 64 positions into the window
+    const u32 fast_hi = tc.xz_hi > tc.xz_lo ? (u32)LW * 64u - 64u : 0u;  // 0: tile with N in reach, no fast path
     const u32 *rec_cnt = smem_rec_cnt();
     const u32 c0 = rec_cnt[0], c1 = c0 + rec_cnt[1], c2 = c1 + rec_cnt[2];
     u32 handled = 0;
@@ -141,7 +220,16 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
             const u64 p = kind == (u32)PRF_KIND_START ? p8 + bit : p8;  // START: the mask selects rows, else motif sizes
             const u32 k = kind == (u32)PRF_KIND_START ? kk : kk + bit;
             u64 a, b;
-            if (prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b)) {
+            u32 fa, fb;
+            int st = 2;
+            if (fast_hi) st = fast_candidate(fh, fl, (u32)(p - win_pos0), k, kind, min_repeats, min_span, fast_lo, fast_hi, fa, fb);
+            if (st == 1) {
+                a = win_pos0 + fa;
+                b = win_pos0 + fb;
+            } else if (st == 2) {
+                st = prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b) ? 1 : 0;
+            }
+            if (st == 1) {
                 const u32 slot = atomicAdd(hit_cnt, 1u);
                 if (slot < hit_cap) {
                     prf_hit_dev h;
