@@ -4,16 +4,16 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: counters reset,
-phase-1 kernel(s), phase-2 kernel, row count back on the host -- on a genome that is already packed and
-resident in HBM when the timed region starts.  Workload (BASELINE.json configs[1]): a
+A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: counters reset, the fused
+scan + verify kernel, the device-side compaction of the rows into one array, row count back on the host -- on a
+genome that is already packed and resident in HBM when the timed region starts.  Workload (BASELINE.json configs[1]): a
 chr22-sized contig (50 818 468 bp), motif sizes 1-50, min_repeats 3, min_span 9.  No genome FASTA exists
 offline, so the contig is the synthetic stand-in of colab-repeat-finder_amd/synth.py (hg38-like N blocks,
 ~1.8 k planted repeats per Mbp, uniform ACGT elsewhere).
 
 N > 1: one process per GPU; every rank scans its own chr22-sized contig (seed 22 + rank; weak scaling, no
 data-path collective) and the rows are then concatenated on rank 0 with one padded RCCL gather, inside
-the timed region.
+the timed region (double-buffered: the gather of step i overlaps the scan of step i+1).
 
 Rank 0 prints ONE JSON line.  `value` is whole-job Gbp/s from the wall clock (max over ranks); the
 `roofline` object prices the dominant kernel (phase 1) with HIP events measured live on the library's
@@ -90,18 +90,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # Rehearsal knobs (never used by the driver): PRF_BENCH_BACKEND=gloo + PRF_BENCH_ONE_GPU=1 run N ranks on ONE GPU
+    # with CPU tensors for the collectives, to exercise the N>1 code path on a single-GPU box.
+    backend = os.environ.get("PRF_BENCH_BACKEND", "nccl")
+    one_gpu = os.environ.get("PRF_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    tdev = "cpu" if backend == "gloo" else "cuda"
     dist = None
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     length = args.length or synth.CHR22_LEN
     n_head = 10_510_000 if length >= 20_000_000 else length // 10
     seq = synth.chr_standin(length=length, seed=22 + rank, n_head=n_head, n_tail=min(10_000, length // 100)).tobytes()
 
-    ctx = prf_native.Context(local_rank)
+    ctx = prf_native.Context(dev_index)
     genome = ctx.load([seq], args.kmax)
     flags = prf_native.SCAN_FORCE_GENERIC if args.generic else prf_native.SCAN_DEFAULT
     scan = lambda fetch: genome.scan(args.kmin, args.kmax, args.min_repeats, args.min_span, flags=flags, fetch=fetch)
@@ -111,22 +119,35 @@ def main():
     n_rows_local = len(rows)
     gather_cap = None
     if world > 1:
-        cap = torch.tensor([n_rows_local], device="cuda", dtype=torch.int64)
+        cap = torch.tensor([n_rows_local], device=tdev, dtype=torch.int64)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
         gather_cap = int(cap.item()) + 1
-        send = torch.zeros((gather_cap, 3), dtype=torch.int64, device="cuda")      # 24-byte rows + count row
-        recv = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
+        # two send buffers: the gather of step i overlaps the scan of step i+1
+        send_devs = [torch.zeros((gather_cap, 3), dtype=torch.int64, device="cuda") for _ in range(2)]  # 24-byte rows + count row
+        sends = send_devs if tdev == "cuda" else [torch.zeros((gather_cap, 3), dtype=torch.int64) for _ in range(2)]
+        recvs = [[torch.zeros_like(sends[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+        pending = [None, None]
+        step_no = [0]
 
     def step():
         _, st = scan(False)
         if world > 1:
-            n = ctx.last_hits_to_device(send.data_ptr(), gather_cap - 1)
-            send[gather_cap - 1, 0] = n
-            dist.gather(send, recv, dst=0)
+            b = step_no[0] & 1
+            step_no[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()                                                # the gather that used this buffer 2 steps ago
+            n = ctx.last_hits_to_device(send_devs[b].data_ptr(), gather_cap - 1)  # device-to-device, rows stay in HBM
+            send_devs[b][gather_cap - 1, 0] = n
+            if sends[b] is not send_devs[b]:
+                sends[b].copy_(send_devs[b])                                     # gloo rehearsal only
+            pending[b] = dist.gather(sends[b], recvs[b], dst=0, async_op=True)
         return st
 
     def fence():
         if world > 1:
+            for w in pending:
+                if w is not None:
+                    w.wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,15 +164,24 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_rows_local], device="cuda", dtype=torch.int64)
+        tot = torch.tensor([n_rows_local], device=tdev, dtype=torch.int64)
         dist.all_reduce(tot)
         n_rows_total = int(tot.item())
     else:
         n_rows_total = n_rows_local
 
+    gathered_ok = None
+    if world > 1 and rank == 0:
+        # the last gather must hold every rank's rows: counts add up and rank 0's part equals its own fetched rows
+        recv = recvs[(step_no[0] - 1) & 1]
+        counts = [int(r[gather_cap - 1, 0].item()) for r in recv]
+        mine = recv[0][:counts[0]].cpu().numpy().view(np.uint8).reshape(-1, 24)
+        ref = np.ascontiguousarray(rows).view(np.uint8).reshape(-1, 24)
+        order = lambda a: a[np.lexsort(a.T[::-1])]
+        gathered_ok = bool(sum(counts) == n_rows_total and counts[0] == n_rows_local and np.array_equal(order(mine), order(ref)))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_bp = length * world
@@ -173,8 +203,8 @@ def main():
                        "kernel_path": "generic" if st0.path == 0 else "vertical",
                        "rows_per_gpu": n_rows_local, "rows_total": n_rows_total,
                        "candidates_per_gpu": int(st0.n_candidates),
-                       "multi_gpu": "one contig per rank, no data-path collective; one padded RCCL gather of rows to rank 0"
-                                    if world > 1 else "n/a"},
+                       "multi_gpu": ("one contig per rank, no data-path collective; one padded RCCL gather of rows to rank 0"
+                                     f" (gather verified: {gathered_ok})") if world > 1 else "n/a"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(length, args.kmin, args.kmax),
                          "kernel": "prf_vscan_kernel (fused scan + verify)" if st0.path == 1 else "prf_scan_generic_kernel",
@@ -182,8 +212,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_alg,
                          "measured_hbm_read_GBps": round(hbm_meas, 1),
                          "frac_of_measured_read": round(achieved / hbm_meas, 5)},
-            "device_ms": {"phase1": round(p1, 5), "phase2": round(float(np.mean(p2_ms)), 5),
-                          "scan": round(float(np.mean(scan_ms)), 5)},
+            "device_ms": {"fused_scan_verify_kernel": round(p1, 5), "row_compaction": round(float(np.mean(p2_ms)), 5),
+                          "total": round(float(np.mean(scan_ms)), 5)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,

@@ -47,8 +47,13 @@ struct prf_ctx {
     int dev = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    u64 *d_counters = nullptr;
-    u64 *h_counters = nullptr;  // pinned
+    u64 *d_counters = nullptr;   // generic path + packer
+    u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
+    u64 *h_counters_dev = nullptr;  // device address of h_counters
+    u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
+    u32 *d_group_sums = nullptr; // fused path: two arrays of per-64-slab row totals, used alternately
+    u64 group_cap = 0;
+    u32 parity = 0;
     // generic path scratch
     u64 *d_cand = nullptr;
     u64 cand_cap = 0;
@@ -63,8 +68,7 @@ struct prf_ctx {
     u64 slab_serial = 0;  // genome whose tile list the slab counts currently reflect
     // where the rows of the last scan are
     u64 last_nhits = 0;
-    bool last_in_slabs = false;  // true: still in per-tile slabs (fused path), compact on demand
-    u64 last_ntiles = 0;
+    bool last_in_slabs = false;
 };
 
 struct prf_genome {
@@ -114,7 +118,10 @@ int prf_open(int device_id, prf_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipMalloc((void **)&c->d_counters, PRF_CNT_N * sizeof(u64)));
-    HIPCHK(hipHostMalloc((void **)&c->h_counters, PRF_CNT_N * sizeof(u64), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_counters, PRF_CNT_N * sizeof(u64), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0));
+    HIPCHK(hipMalloc((void **)&c->d_vcounters, 2 * PRF_CNT_N * sizeof(u64)));
+    HIPCHK(hipMemset(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64)));
     *out = c;
     return PRF_OK;
 }
@@ -125,6 +132,8 @@ void prf_close(prf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_counters);
     (void)hipHostFree(c->h_counters);
+    (void)hipFree(c->d_vcounters);
+    (void)hipFree(c->d_group_sums);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_hit_slabs);
@@ -283,24 +292,20 @@ static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap, u64 serial) {
         HIPCHK(hipMalloc((void **)&c->d_hit_slabs, ntiles * (u64)cap * sizeof(prf_hit_dev)));
         HIPCHK(hipMalloc((void **)&c->d_hit_counts, ntiles * sizeof(u32)));
         HIPCHK(hipMalloc((void **)&c->d_offsets, (ntiles + 1) * sizeof(u64)));
+        {
+            const u64 ng = (ntiles + 63) / 64;
+            (void)hipFree(c->d_group_sums);
+            c->d_group_sums = nullptr;
+            HIPCHK(hipMalloc((void **)&c->d_group_sums, 2 * ng * sizeof(u32)));
+            HIPCHK(hipMemsetAsync(c->d_group_sums, 0, 2 * ng * sizeof(u32), c->stream));
+            c->group_cap = ng;
+        }
         // tiles that are never launched (nothing but N) must read as empty
         HIPCHK(hipMemsetAsync(c->d_hit_counts, 0, ntiles * sizeof(u32), c->stream));
         c->slab_tiles = ntiles;
         c->slab_cap = cap;
         c->slab_serial = serial;
     }
-    return PRF_OK;
-}
-
-// fused path: rows of the last scan, per-tile slabs -> c->d_hits (compact, tile order)
-static int compact_last(prf_ctx *c) {
-    if (!c->last_in_slabs) return PRF_OK;
-    int rc = ensure_buffers(c, c->cand_cap, std::max<u64>(c->hit_cap, c->last_nhits + 1));
-    if (rc) return rc;
-    HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, c->last_ntiles, c->d_offsets,
-                                   c->d_hits));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->last_in_slabs = false;
     return PRF_OK;
 }
 
@@ -348,22 +353,34 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.hit_slabs = c->d_hit_slabs; a.hit_counts = c->d_hit_counts; a.hit_cap = c->slab_cap;
             a.min_repeats = min_repeats; a.min_span = min_span;
             a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
-            a.counters = c->d_counters;
+            u64 *cur_counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
+            u64 *nxt_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
+            u32 *cur_groups = c->d_group_sums + (size_t)c->parity * c->group_cap;
+            u32 *nxt_groups = c->d_group_sums + (size_t)(c->parity ^ 1u) * c->group_cap;
+            c->parity ^= 1u;
+            a.counters = cur_counters;
+            a.group_sums = cur_groups;
             a.dbg = nullptr;
 #ifdef PRF_STAMPS
             static u64 *dbg_buf = nullptr;
             if (!dbg_buf) HIPCHK(hipMalloc((void **)&dbg_buf, (size_t)(1 << 20) * 32 * sizeof(u64)));
             a.dbg = dbg_buf;
 #endif
-            HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+            rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
+            if (rc) return rc;
+            // three calls into the runtime per scan: two kernels and one synchronise (+ event records); the counter
+            // block for this scan was cleared on the device by the previous scan's compaction kernel
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
             HIPCHK(prf_vertical_launch(c->stream, a));
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
-            HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            // rows of the per-tile slabs -> one compact array; counters -> mapped host memory
+            HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, nslabs, cur_groups,
+                                           c->d_hits, c->hit_cap, cur_counters, c->h_counters_dev, nxt_counters, nxt_groups));
+            HIPCHK(hipEventRecord(c->ev[2], c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
-            ms12 = 0;
-            launches = 1;
+            HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
+            launches = 2;
             ncand = nhits = 0;
             for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) {
                 nhits += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_HITS];
@@ -383,10 +400,17 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                         (unsigned long long)c->h_counters[PRF_CNT_REC_OVF], (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
-            if (!again) {
-                c->last_in_slabs = true;
-                c->last_ntiles = nslabs;
+            if (!again && nhits > c->hit_cap) {  // the compact array was too small: grow it and gather again
+                want_hits = nhits + nhits / 8 + 1024;
+                rc = ensure_buffers(c, c->cand_cap, want_hits);
+                if (rc) return rc;
+                // (the counters were already cleared for the next scan: gather with the same group sums, and clear
+                // the same "next" arrays again, which is harmless)
+                HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, nslabs, cur_groups,
+                                               c->d_hits, c->hit_cap, cur_counters, c->h_counters_dev, nxt_counters, nxt_groups));
+                HIPCHK(hipStreamSynchronize(c->stream));
             }
+            c->last_in_slabs = false;
         } else {
             // ---- generic path: candidates, then rows ----
             int rc = ensure_buffers(c, want_cand, want_hits);
@@ -426,10 +450,6 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
     if (nhits == 0) return PRF_OK;
-    {
-        int rc = compact_last(c);
-        if (rc) return rc;
-    }
     prf_hit *rows = (prf_hit *)malloc(nhits * sizeof(prf_hit));
     if (!rows) return fail(PRF_ENOMEM, "prf_scan_genome: cannot allocate %llu rows", (unsigned long long)nhits);
     static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
@@ -474,10 +494,6 @@ int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, uint6
     if (!c || !n_rows || (capacity_rows && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
     HIPCHK(hipSetDevice(c->dev));
     *n_rows = c->last_nhits;
-    if (c->last_nhits) {
-        int rc = compact_last(c);
-        if (rc) return rc;
-    }
     const u64 n = std::min<u64>(c->last_nhits, capacity_rows);
     if (n) {
         HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));

@@ -575,7 +575,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
     if (tid == 0) {
         const u32 n = *hit_cnt;
-        g.hit_counts[tile * 4 + part] = n < g.hit_cap ? n : g.hit_cap;
+        const u32 stored = n < g.hit_cap ? n : g.hit_cap;
+        g.hit_counts[tile * 4 + part] = stored;
+        if (stored) atomicAdd(&g.group_sums[(tile * 4 + part) >> 6], stored);  // rows per 64 slabs, for the compaction
         atomicAdd(&sh[PRF_SH_HITS], (u64)n);
         if (n > g.hit_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
     }
@@ -636,51 +638,66 @@ __global__ void prf_tile_class_kernel(const unsigned char *__restrict__ any_all,
     cls[i] = (a & 2) ? 2 : (((a | b) & 1) ? 1 : 0);
 }
 
-// ---- rows of the per-tile slabs -> one compact array in tile order ----
-// exclusive scan of the per-tile counts by ONE workgroup (ntiles is at most a few 10^4), offsets[ntiles] = total
-__global__ __launch_bounds__(1024) void prf_scan_counts_kernel(const u32 *__restrict__ counts, u64 ntiles, u64 *__restrict__ offsets) {
-    __shared__ u64 part[1024];
-    const u32 tid = threadIdx.x;
-    const u64 per = (ntiles + 1023) / 1024;
-    const u64 lo = (u64)tid * per < ntiles ? (u64)tid * per : ntiles;
-    const u64 hi = lo + per < ntiles ? lo + per : ntiles;
-    u64 sum = 0;
-    for (u64 i = lo; i < hi; i++) sum += counts[i];
-    part[tid] = sum;
+// ---- rows of the per-tile slabs -> one compact array in slab order, ONE launch ----
+// Block g owns the 64 slabs [64g, 64g+64).  Its offset = sum of the per-group row totals of the groups before it
+// (group_sums, accumulated by the scan kernel) + an exclusive scan of its own 64 counts.  The last block also
+// hands the scan's counters to the host (mapped pinned memory: no copy call) and every block clears its share
+// of the OTHER parity's counters / group sums, which the next scan will use (no memset call).
+__global__ __launch_bounds__(256) void prf_compact_hits_kernel(const prf_hit_dev *__restrict__ slabs, const u32 *__restrict__ counts,
+                                                               u32 hit_cap, u64 nslabs, const u32 *__restrict__ group_sums,
+                                                               prf_hit_dev *__restrict__ out, u64 out_cap,
+                                                               const u64 *__restrict__ counters, u64 *__restrict__ host_counters,
+                                                               u64 *__restrict__ next_counters, u32 *__restrict__ next_group_sums,
+                                                               u32 ngroups) {
+    __shared__ u64 red[256];
+    __shared__ u64 slab_off[64];
+    const u32 g = blockIdx.x >> 3, sub = blockIdx.x & 7u, tid = threadIdx.x;  // 8 blocks per group: 8 slabs each
+    u64 before = 0;
+    for (u32 j = tid; j < g; j += 256) before += group_sums[j];
+    red[tid] = before;
     __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        const u64 v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
+    for (u32 d = 128; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
         __syncthreads();
     }
-    u64 run = part[tid] - sum;
-    for (u64 i = lo; i < hi; i++) {
-        offsets[i] = run;
-        run += counts[i];
+    const u64 base = red[0];
+    if (tid < 64) {  // exclusive scan of the 64 counts by one wave
+        const u64 slab = (u64)g * 64 + tid;
+        const u32 n = slab < nslabs ? counts[slab] : 0u;
+        u32 incl = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 v = __shfl_up(incl, d);
+            if ((int)tid >= d) incl += v;
+        }
+        slab_off[tid] = base + incl - n;
     }
-    if (tid == 1023) offsets[ntiles] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void prf_gather_hits_kernel(const prf_hit_dev *__restrict__ slabs, const u32 *__restrict__ counts,
-                                                              u32 hit_cap, const u64 *__restrict__ offsets,
-                                                              prf_hit_dev *__restrict__ out) {
-    const u64 tile = blockIdx.x;
-    const u32 n = counts[tile];
-    const prf_hit_dev *src = slabs + tile * (u64)hit_cap;
-    prf_hit_dev *dst = out + offsets[tile];
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    for (u32 sidx = sub * 8; sidx < sub * 8 + 8; sidx++) {
+        const u64 slab = (u64)g * 64 + sidx;
+        if (slab >= nslabs) break;
+        const u32 n = counts[slab];
+        const u64 off = slab_off[sidx];
+        if (n == 0 || off + n > out_cap) continue;  // too small an output array: the host sees the total and retries
+        const prf_hit_dev *src = slabs + slab * (u64)hit_cap;
+        for (u32 i = tid; i < n; i += 256) out[off + i] = src[i];
+    }
+    // housekeeping for the host and for the next scan
+    if (blockIdx.x == gridDim.x - 1) {
+        for (u32 i = tid; i < (u32)PRF_CNT_N; i += 256) host_counters[i] = counters[i];
+    }
+    for (u32 i = blockIdx.x * 256 + tid; i < (u32)PRF_CNT_N; i += gridDim.x * 256) next_counters[i] = 0;
+    for (u32 i = blockIdx.x * 256 + tid; i < ngroups; i += gridDim.x * 256) next_group_sums[i] = 0;
 }
 
 }  // namespace
 
 hipError_t prf_launch_compact_hits(hipStream_t s, const prf_hit_dev *hit_slabs, const u32 *hit_counts, u32 hit_cap,
-                                   u64 ntiles, u64 *offsets, prf_hit_dev *out) {
-    if (ntiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(prf_scan_counts_kernel, dim3(1), dim3(1024), 0, s, hit_counts, ntiles, offsets);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(prf_gather_hits_kernel, dim3((u32)ntiles), dim3(256), 0, s, hit_slabs, hit_counts, hit_cap, offsets, out);
+                                   u64 nslabs, const u32 *group_sums, prf_hit_dev *out, u64 out_cap, const u64 *counters,
+                                   u64 *host_counters, u64 *next_counters, u32 *next_group_sums) {
+    const u32 ngroups = (u32)((nslabs + 63) / 64);
+    if (ngroups == 0) return hipSuccess;
+    hipLaunchKernelGGL(prf_compact_hits_kernel, dim3(ngroups * 8), dim3(256), 0, s, hit_slabs, hit_counts, hit_cap, nslabs,
+                       group_sums, out, out_cap, counters, host_counters, next_counters, next_group_sums, ngroups);
     return hipGetLastError();
 }
 
