@@ -350,6 +350,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.H = g->H; a.L = g->L; a.X = g->X;
             a.tile_list = g->vp.tile_list;
             a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
+            a.clean_base = g->vp.clean_base;
             a.hit_slabs = c->d_hit_slabs; a.hit_counts = c->d_hit_counts; a.hit_cap = c->slab_cap;
             a.min_repeats = min_repeats; a.min_span = min_span;
             a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();

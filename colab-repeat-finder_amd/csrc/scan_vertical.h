@@ -13,6 +13,7 @@ struct prf_vplanes {
     unsigned char *tile_class = nullptr;  // per tile: 0 clean, 1 has not-ACGT positions in reach, 2 nothing but not-ACGT
     u32 *tile_list = nullptr;             // device: clean tiles, then mixed tiles (the sentinel tile excluded)
     u32 n_clean = 0, n_mixed = 0;
+    u32 clean_base = ~0u;                 // first clean tile if they form one contiguous range
     u64 ntiles_alloc = 0;
 };
 
@@ -43,6 +44,7 @@ struct prf_vscan_args {
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
     const u32 *tile_list;          // clean tiles first, then mixed
     u32 n_clean, n_mixed;
+    u32 clean_base;                // first clean tile if the clean tiles are one contiguous range, else ~0u
     prf_hit_dev *hit_slabs;        // [tile*4 + part][hit_cap]  (clean tiles use part 0 only)
     u32 *hit_counts;               // [tile*4 + part]
     u32 *group_sums;               // [(tile*4 + part) / 64]: rows per 64 slabs (zero when the kernel starts)
