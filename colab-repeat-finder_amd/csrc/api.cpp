@@ -388,8 +388,15 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
             }
 #ifdef PRF_STAMPS
+            if (getenv("PRF_STAMPS_OUT")) {
+                fprintf(stderr, "[prf] plan: %u waves, %u tasks\n", a.plan.n_waves, a.plan.n_tasks);
+                for (u32 w = 0; w < a.plan.n_waves; w++)
+                    for (u32 ti = a.plan.wave_begin[w]; ti < a.plan.wave_begin[w + 1]; ti++)
+                        fprintf(stderr, "[prf]   wave %u slot %u: kind %u k0 %u valid %02x stride %u\n", w, ti - a.plan.wave_begin[w],
+                                a.plan.tasks[ti].kind, a.plan.tasks[ti].k0, a.plan.tasks[ti].valid, a.plan.tasks[ti].stride);
+            }
             if (const char *path = getenv("PRF_STAMPS_OUT")) {
-                const size_t nu = (size_t)(a.n_clean + a.n_mixed) * 4 * 8;
+                const size_t nu = (size_t)(a.n_clean + 4 * a.n_mixed) * 4 * 16;
                 std::vector<u64> host(nu);
                 HIPCHK(hipMemcpy(host.data(), a.dbg, nu * sizeof(u64), hipMemcpyDeviceToHost));
                 if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, nu, f); fclose(f); }

@@ -47,7 +47,7 @@
 #ifdef PRF_STAMPS
 #define PRF_STAMP(i)                                                                          \
     do {                                                                                      \
-        if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define PRF_STAMP(i) do { } while (0)
@@ -450,10 +450,14 @@ __device__ __forceinline__ void exact_task_any(const uint4 *vimg, int lane, u32 
 }
 
 template <bool HASX, int NC>
-__device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &plan, int wave, int lane, int tb0, int tb1, Emit &em) {
+__device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &plan, int wave, int lane, int tb0, int tb1, Emit &em,
+                                          u64 *dbg = nullptr) {
     const u32 t_end = plan.wave_begin[wave + 1];
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
         const prf_vtask task = plan.tasks[ti];
+#ifdef PRF_STAMPS
+        if (dbg && lane == 0) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
+#endif
         switch (task.kind) {
             case 0: group_task<HASX, NC>(vimg, lane, task.k0, task.valid, task.stride, tb0, tb1, em); break;
             case 1: exact_task_any<1, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
@@ -619,8 +623,13 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     em.handled = 0;
     em.lane_pos = tile * PRF_TILE + (u64)lane * T;
     em.lane = lane;
-    if (hasx) run_tasks<true, NC>(vimg, g.plan, wave, lane, tb0, tb1, em);
-    else run_tasks<false, NC>(vimg, g.plan, wave, lane, tb0, tb1, em);
+#ifdef PRF_STAMPS
+    u64 *task_dbg = g.dbg ? g.dbg + ((u64)blockIdx.x * MAX_WAVES + wave) * 16 : nullptr;
+#else
+    u64 *task_dbg = nullptr;
+#endif
+    if (hasx) run_tasks<true, NC>(vimg, g.plan, wave, lane, tb0, tb1, em, task_dbg);
+    else run_tasks<false, NC>(vimg, g.plan, wave, lane, tb0, tb1, em, task_dbg);
     if (lane == 0) rec_cnt[wave] = em.cnt;  // waves the plan does not use keep the 0 from staging
     PRF_STAMP(3);
     __syncthreads();
@@ -782,7 +791,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
             it.t.stride = 1;
-            it.cost = 40 + (u32)(8 + M - 1) * 12;  // per block: single-dword reads of the shifted rows + ~5 VALU per row
+            it.cost = 88;  // measured (stamps build, chr22 stand-in): 7.5-9.9 k cycles per exact task, whatever M
             items.push_back(it);
             const u32 nr = 8 + (u32)M - 1;  // rows per block; whole 16-byte slots are read
             reach = std::max<u32>(reach, (k & ~3u) + 4 * (((k & 3u) + nr + 3) / 4) - 1);
@@ -804,7 +813,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            it.cost = (40 + 20 * (u32)__builtin_popcount(valid)) / stride + 10;
+            it.cost = 8 + 27 * (4 / stride);  // measured: ~2.7 k cycles per examined block + ~0.8 k per task
             items.push_back(it);
             reach = std::max<u32>(reach, k0 + 15);
             covered_to = k0 + 8;

@@ -12,7 +12,7 @@ for _ in range(3):
     g.scan(1, 50, 3, 9, fetch=False)
 _, st = g.scan(1, 50, 3, 9, fetch=False)
 print('kernel ms', st.phase1_ms)
-d = np.fromfile(os.environ['PRF_STAMPS_OUT'], dtype=np.uint64).reshape(-1, 4, 8).astype(np.int64)
+d = np.fromfile(os.environ['PRF_STAMPS_OUT'], dtype=np.uint64).reshape(-1, 4, 16).astype(np.int64)
 t0 = d[:, :, 0].min()
 names = ['stage', 'bar1', 'scan', 'bar2', 'verify', 'bar3']
 for w in range(4):
@@ -26,3 +26,13 @@ print('last 4 WGs (mixed tiles are last):', tot[-4:])
 order = np.argsort(tot)[-6:]
 for i in order:
     print('slow WG', int(i), 'total', int(tot[i]), 'phases w0', [int(d[i, 0, j + 1] - d[i, 0, j]) for j in range(6)])
+
+# per-task durations (cycles, median over workgroups): slot 8+i = start of the wave's i-th task, slot 3 = end of scan
+for w in range(4):
+    starts = [d[:, w, 8 + i] for i in range(6)]
+    out = []
+    for i in range(6):
+        if np.median(starts[i]) == 0: break
+        nxt = starts[i + 1] if i + 1 < 6 and np.median(starts[i + 1]) != 0 else d[:, w, 3]
+        out.append(int(np.median(nxt - starts[i])))
+    print('wave', w, 'task cycles', out)
