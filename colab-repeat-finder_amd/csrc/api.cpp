@@ -510,6 +510,33 @@ int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, uint6
     return PRF_OK;
 }
 
+int prf_plan_describe(uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span, char *buf, uint64_t buf_len) {
+    if (!buf || buf_len == 0) return fail(PRF_EINVAL, "prf_plan_describe: no buffer");
+    std::string out;
+    prf_vplan plan;
+    if (!prf_vertical_plan(kmin, kmax, min_repeats, min_span, &plan)) {
+        out = "{\"path\": \"generic\"}";
+    } else {
+        char tmp[160];
+        snprintf(tmp, sizeof tmp, "{\"path\": \"fused\", \"waves\": %u, \"nc\": %u, \"lds_bytes\": %u, \"tasks\": [", plan.n_waves,
+                 plan.nc, plan.lds_bytes);
+        out = tmp;
+        bool first = true;
+        for (u32 w = 0; w < plan.n_waves; w++)
+            for (u32 ti = plan.wave_begin[w]; ti < plan.wave_begin[w + 1]; ti++) {
+                const prf_vtask &t = plan.tasks[ti];
+                snprintf(tmp, sizeof tmp, "%s{\"wave\": %u, \"kind\": %u, \"k0\": %u, \"valid\": %u, \"stride\": %u}", first ? "" : ", ",
+                         w, (unsigned)t.kind, (unsigned)t.k0, (unsigned)t.valid, (unsigned)t.stride);
+                out += tmp;
+                first = false;
+            }
+        out += "]}";
+    }
+    if (out.size() + 1 > buf_len) return fail(PRF_EINVAL, "prf_plan_describe: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}
+
 void prf_free_hits(prf_hits *h) {
     if (!h) return;
     free(h->rows);

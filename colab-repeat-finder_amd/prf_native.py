@@ -54,7 +54,7 @@ class ScanStats(ctypes.Structure):
 
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
-           "prf_measure_hbm_read", "prf_last_hits_to_device"]
+           "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -91,6 +91,7 @@ def load_library():
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         _lib = lib
         return lib
 
@@ -202,6 +203,17 @@ class Context:
         if self._h is not None:
             self.lib.prf_close(self._h)
             self._h = None
+
+
+def plan_describe(kmin, kmax, min_repeats, min_span):
+    """Host-only: the fused kernel's work plan for these parameters, as a dict (no GPU needed)."""
+    import json
+    lib = load_library()
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = lib.prf_plan_describe(kmin, kmax, min_repeats, min_span, buf, len(buf))
+    if rc < 0:
+        raise PrfError(rc, lib.prf_last_error().decode("utf-8", "replace"))
+    return json.loads(buf.value.decode())
 
 
 _default_ctx = {}

@@ -120,6 +120,12 @@ void prf_free_hits(prf_hits *hits);
  * an RCCL gather then ships to rank 0).  *n_rows receives the row count; at most capacity_rows are copied. */
 int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, uint64_t *n_rows);
 
+/* Host-only: describe, as one line of JSON, how a scan with these parameters is dealt to the waves of the fused
+ * kernel (tasks, motif sizes, examined-group strides) or that the generic kernel is used.  Needs no GPU; used by
+ * the CPU tests to check that every motif size is covered exactly once and that the sampling strides are legal.
+ * Returns the length written (excluding the NUL), or PRF_EINVAL if buf is too small. */
+int prf_plan_describe(uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span, char *buf, uint64_t buf_len);
+
 /* Roofline probe: streaming 16-byte-per-lane read of `bytes` bytes, best of `iters`; GB/s (1e9). */
 int prf_measure_hbm_read(prf_ctx *ctx, uint64_t bytes, int iters, double *gbps);
 

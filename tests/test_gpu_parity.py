@@ -192,3 +192,27 @@ def test_full_size_chr22_standin_vs_oracle(ctx):
     assert starts.min() >= 10_510_000 and ends.max() <= len(seq) - 10_000
     want = oracle_rows(seq, 1, 50, 3, 9)
     assert got == want
+
+
+def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
+    """The drop-in command line end to end on the GPU: multi-contig FASTA -> BED, literal sequence -> TSV."""
+    import argparse
+    import perfect_repeat_finder as prf
+    import synth
+    from oracle import prf_oracle
+    monkeypatch.chdir(tmp_path)
+    contigs = {"chrA": synth.chr_standin(length=90_000, seed=31, n_head=5_000, n_tail=500, repeats_per_mbp=3000).tobytes().decode(),
+               "chrB": "acgt" * 10 + "N" * 7 + "CAGCAGCAGCAGCAGCAG" + "TTTTTTTTTTTTT",
+               "chrC": ""}
+    with open("toy.fasta", "wt") as f:
+        for name, seq in contigs.items():
+            f.write(f">{name} test\n")
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+    prf.main(["toy.fasta"])
+    fs = argparse.Namespace(min_motif_size=1, max_motif_size=50, min_repeats=3, min_span=9)
+    want = "".join(f"{name}\t{s}\t{e}\t{m}\n" for name, seq in contigs.items() for s, e, m in prf_oracle.detect_repeats(seq, fs))
+    assert open("toy.bed").read() == want and want.count("\n") > 100
+    prf.main(["-min", "2", "-max", "6", "CACACACACACAGGGTTTTTTTTTTT"])
+    assert open("repeats.tsv").read() == "start_0based\tend\tmotif\n0\t12\tCA\n"
+    assert "Found 1 repeats" in capsys.readouterr().out

@@ -1,0 +1,55 @@
+"""CPU: the host-side work planner of the fused kernel (prf_vertical_plan through prf_plan_describe).
+Every motif size must be scanned exactly once, by the right kind of task, and a chunk may skip aligned groups
+(stride 2 / 4) only if every motif size in it needs runs long enough to contain an examined group."""
+import itertools
+
+import prf_native
+
+
+def M(k, r, span):
+    return max((r - 1) * k, span - k)
+
+
+def check(kmin, kmax, r, span):
+    plan = prf_native.plan_describe(kmin, kmax, r, span)
+    if kmax > 480:
+        assert plan["path"] == "generic"
+        return plan
+    assert plan["path"] == "fused" and 1 <= plan["waves"] <= 4
+    seen = {}
+    for t in plan["tasks"]:
+        assert 0 <= t["wave"] < plan["waves"]
+        if t["kind"] == 0:
+            assert t["k0"] % 4 == 0 and t["stride"] in (1, 2, 4)
+            ks = [t["k0"] + i for i in range(8) if (t["valid"] >> i) & 1]
+            assert ks
+            for k in ks:
+                assert M(k, r, span) >= 15                       # groups of 8 rows need runs of >= 15
+                assert M(k, r, span) >= 8 * t["stride"] + 7      # a run that long contains an examined group
+        else:
+            ks = [t["k0"]]
+            assert t["kind"] == M(t["k0"], r, span) < 15          # exact task, templated on M
+        for k in ks:
+            assert k not in seen, (k, t, seen[k])
+            seen[k] = t
+    assert sorted(seen) == list(range(kmin, kmax + 1))
+    # the LDS image must be wide enough for the furthest row any task reads
+    reach = max([t["k0"] + 15 for t in plan["tasks"] if t["kind"] == 0] +
+                [(t["k0"] & ~3) + 4 * (((t["k0"] & 3) + 8 + t["kind"] - 1 + 3) // 4) - 1 for t in plan["tasks"] if t["kind"]])
+    assert plan["nc"] >= 64 + (24 + reach) // 32 and plan["lds_bytes"] <= 160 * 1024 // 3
+    return plan
+
+
+def test_default_parameters():
+    plan = check(1, 50, 3, 9)
+    assert plan["waves"] == 4
+    strides = {t["k0"]: t["stride"] for t in plan["tasks"] if t["kind"] == 0}
+    assert strides == {8: 1, 16: 2, 24: 4, 32: 4, 40: 4, 48: 4}
+    assert sorted(t["k0"] for t in plan["tasks"] if t["kind"]) == [1, 2, 3, 4, 5, 6, 7]
+
+
+def test_parameter_sweep():
+    for kmin, width, r, span in itertools.product((1, 2, 3, 5, 9, 16, 33), (0, 1, 5, 17, 50, 130), (2, 3, 4, 7), (1, 5, 9, 14, 15, 16, 30, 200)):
+        check(kmin, kmin + width, r, span)
+    check(1, 480, 3, 9)
+    check(300, 481, 2, 5)
