@@ -29,10 +29,12 @@ for i in order:
 
 # per-task durations (cycles, median over workgroups): slot 8+i = start of the wave's i-th task, slot 3 = end of scan
 for w in range(4):
-    starts = [d[:, w, 8 + i] for i in range(6)]
+    starts = [d[:, w, 8 + i] for i in range(4)]
     out = []
-    for i in range(6):
+    for i in range(4):
         if np.median(starts[i]) == 0: break
-        nxt = starts[i + 1] if i + 1 < 6 and np.median(starts[i + 1]) != 0 else d[:, w, 3]
+        nxt = starts[i + 1] if i + 1 < 4 and np.median(starts[i + 1]) != 0 else d[:, w, 3]
         out.append(int(np.median(nxt - starts[i])))
     print('wave', w, 'task cycles', out)
+for w in range(4):
+    print('wave', w, 'exact blocks: rows(load+mismatch words)=%d cand(incl push)=%d push=%d cycles total, hot blocks=%d' % tuple(int(np.median(d[:, w, 12 + i])) for i in range(4)))
