@@ -215,7 +215,7 @@ def main():
             "device_ms": {"fused_scan_verify_kernel": round(p1, 5), "row_compaction": round(float(np.mean(p2_ms)), 5),
                           "total": round(float(np.mean(scan_ms)), 5)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,
                                                args.cpu_sample_bp)
         print(json.dumps(out), flush=True)
