@@ -35,6 +35,17 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// for the other host-side translation units of the library
+int prf_set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \

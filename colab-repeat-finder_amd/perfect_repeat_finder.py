@@ -148,41 +148,50 @@ def _build_parser():
     return p
 
 
+def _scan_whole_fasta(fasta, bed_path, fs, report):
+    """Every contig of the FASTA: one resident genome, one scan, BED written by libprf (reference :135-149 loops
+    over the contigs one detect_repeats() call at a time).  report(entry, n_rows) is called per contig in order."""
+    if fs.min_repeats < 2:
+        raise NotImplementedError("min_repeats == 1 is not supported on the GPU path (see _gpu_rows)")
+    try:
+        prf_native.scan_fasta_to_bed(prf_native.default_context(), fasta, bed_path, fs.min_motif_size, fs.max_motif_size,
+                                     fs.min_repeats, fs.min_span, on_contig=report)
+    except prf_native.PrfError as exc:
+        if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
+            raise ValueError(exc.message) from None
+        raise
+
+
 def _scan_fasta(args, parser):
-    from fasta import Fasta
     if not args.output_prefix:
         args.output_prefix = re.sub(".fa(sta)?(.gz)?", "", args.input_sequence)   # same unanchored pattern as reference :114
     bed_path = f"{os.path.basename(args.output_prefix)}.bed"
-    entries = Fasta(args.input_sequence)
-    whole_contigs = True
-    if args.interval:
-        parts = re.split("[:-]", args.interval)
-        if len(parts) != 3:
-            parser.error("Invalid --interval format. Must be chrom:start_0based-end")
-        args.interval_chrom = parts[0]
-        args.interval_start_0based = int(parts[1])
-        args.interval_end = int(parts[2])
-        if args.interval_chrom not in entries:
-            parser.error(f"Chromosome {args.interval_chrom} not found in the input FASTA file")
-        entries = [entries[args.interval_chrom]]
-        whole_contigs = False
+    entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
+    if not args.interval:
+        # the reference crashes here without --interval (:139); scan every contig whole instead
+        def report(entry, n_rows):
+            print(f"Processing {entry.name} ({len(entry):,d} bp)")
+            print(f"Found {n_rows:,d} repeats")
+        _check_settings(args)
+        _scan_whole_fasta(entries, bed_path, args, report)
+        print(f"Wrote results to {bed_path}")
+        return
+    parts = re.split("[:-]", args.interval)
+    if len(parts) != 3:
+        parser.error("Invalid --interval format. Must be chrom:start_0based-end")
+    args.interval_chrom = parts[0]
+    args.interval_start_0based = int(parts[1])
+    args.interval_end = int(parts[2])
+    if args.interval_chrom not in entries:
+        parser.error(f"Chromosome {args.interval_chrom} not found in the input FASTA file")
+    entry = entries[args.interval_chrom]
+    seq = entry.seq
+    args.interval_end = min(args.interval_end, len(seq))
     with open(bed_path, "wt") as bed:
-        for entry in entries:
-            seq = entry.seq
-            shown = len(seq)
-            settings = args
-            if whole_contigs:
-                # the reference crashes here without --interval (:139); scan the whole contig instead
-                settings = argparse.Namespace(min_motif_size=args.min_motif_size, max_motif_size=args.max_motif_size,
-                                              min_repeats=args.min_repeats, min_span=args.min_span)
-            else:
-                args.interval_end = min(args.interval_end, len(seq))
-                shown = args.interval_end - args.interval_start_0based
-            print(f"Processing {entry.name} ({shown:,d} bp)")
-            rows = detect_repeats(seq, settings, verbose=args.verbose, show_progress_bar=args.show_progress_bar,
-                                  debug=args.debug)
-            print(f"Found {len(rows):,d} repeats")
-            bed.writelines(f"{entry.name}\t{s}\t{e}\t{m}\n" for s, e, m in rows)
+        print(f"Processing {entry.name} ({args.interval_end - args.interval_start_0based:,d} bp)")
+        rows = detect_repeats(seq, args, verbose=args.verbose, show_progress_bar=args.show_progress_bar, debug=args.debug)
+        print(f"Found {len(rows):,d} repeats")
+        bed.writelines(f"{entry.name}\t{s}\t{e}\t{m}\n" for s, e, m in rows)
     print(f"Wrote results to {bed_path}")
 
 

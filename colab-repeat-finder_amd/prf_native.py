@@ -32,7 +32,7 @@ class PrfError(RuntimeError):
 
 
 class _Contig(ctypes.Structure):
-    _fields_ = [("ascii", ctypes.c_char_p), ("len", ctypes.c_uint64)]
+    _fields_ = [("ascii", ctypes.c_void_p), ("len", ctypes.c_uint64)]
 
 
 class _Hit(ctypes.Structure):
@@ -54,7 +54,8 @@ class ScanStats(ctypes.Structure):
 
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
-           "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe"]
+           "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -92,6 +93,16 @@ def load_library():
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
+        lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+        lib.prf_fasta_count.argtypes = [vp]
+        lib.prf_fasta_entry.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                        ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_fasta_close.argtypes = [vp]
+        lib.prf_fasta_close.restype = None
+        lib.prf_write_bed.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_Contig),
+                                      ctypes.c_int, ctypes.POINTER(_Hits), ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_write_tsv.argtypes = [ctypes.c_char_p, ctypes.POINTER(_Contig), ctypes.POINTER(_Hits),
+                                      ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
         return lib
 
@@ -102,13 +113,21 @@ def _check(lib, rc):
 
 
 def _contig_array(seqs):
+    """(array, keep-alive list).  seqs: bytes objects, or (address, length) pairs of memory that outlives the call."""
     arr = (_Contig * max(1, len(seqs)))()
+    keep = []
     for i, s in enumerate(seqs):
-        if not isinstance(s, (bytes, bytearray)):
+        if isinstance(s, tuple):
+            arr[i].ascii, arr[i].len = s
+            continue
+        if isinstance(s, bytearray):
+            s = bytes(s)
+        if not isinstance(s, bytes):
             raise TypeError("contigs must be bytes")
-        arr[i].ascii = bytes(s) if isinstance(s, bytearray) else s
+        keep.append(s)
+        arr[i].ascii = ctypes.cast(ctypes.c_char_p(s), ctypes.c_void_p)
         arr[i].len = len(s)
-    return arr
+    return arr, keep
 
 
 def _rows(hits):
@@ -172,13 +191,13 @@ class Context:
         self.device = device
 
     def load(self, seqs, kmax_hint):
-        arr = _contig_array(seqs)
+        arr, _keep = _contig_array(seqs)
         g = ctypes.c_void_p()
         _check(self.lib, self.lib.prf_genome_load(self._h, arr, len(seqs), kmax_hint, ctypes.byref(g)))
         return Genome(self, g, len(seqs))
 
     def scan(self, seqs, kmin, kmax, min_repeats, min_span, flags=SCAN_DEFAULT):
-        arr = _contig_array(seqs)
+        arr, _keep = _contig_array(seqs)
         hits = _Hits()
         stats = ScanStats()
         _check(self.lib, self.lib.prf_scan(self._h, arr, len(seqs), kmin, kmax, min_repeats, min_span, flags,
@@ -203,6 +222,81 @@ class Context:
         if self._h is not None:
             self.lib.prf_close(self._h)
             self._h = None
+
+
+class Fasta:
+    """FASTA file read by libprf (plain or gzip): entries in file order; the sequence bytes stay in native memory."""
+
+    class Entry:
+        def __init__(self, name, addr, length):
+            self.name, self.addr, self.length = name, addr, length
+
+        def __len__(self):
+            return self.length
+
+        @property
+        def seq(self):
+            return ctypes.string_at(self.addr, self.length).decode("ascii", "replace") if self.length else ""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.prf_fasta_open(os.fsencode(path), ctypes.byref(h)))
+        self._h = h
+        self.entries = []
+        for i in range(self.lib.prf_fasta_count(h)):
+            name, seq, n = ctypes.c_char_p(), ctypes.c_void_p(), ctypes.c_uint64()
+            _check(self.lib, self.lib.prf_fasta_entry(h, i, ctypes.byref(name), ctypes.byref(seq), ctypes.byref(n)))
+            self.entries.append(Fasta.Entry(name.value.decode(), seq.value or 0, n.value))
+        self._by_name = {}
+        for e in self.entries:
+            self._by_name.setdefault(e.name, e)
+
+    def __iter__(self):
+        return iter(self.entries)
+
+    def __len__(self):
+        return len(self.entries)
+
+    def __contains__(self, name):
+        return name in self._by_name
+
+    def __getitem__(self, key):
+        return self.entries[key] if isinstance(key, int) else self._by_name[key]
+
+    def close(self):
+        if self._h is not None:
+            self.lib.prf_fasta_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scan_fasta_to_bed(ctx, fasta, bed_path, kmin, kmax, min_repeats, min_span, on_contig=None):
+    """All contigs of a FASTA in ONE resident genome and one scan; BED written by libprf.  Returns rows per contig.
+    on_contig(entry, n_rows) is called per contig in file order (the CLI prints the reference's lines there)."""
+    lib = ctx.lib
+    entries = list(fasta)
+    arr, _keep = _contig_array([(e.addr, e.length) for e in entries])
+    hits, stats = _Hits(), ScanStats()
+    _check(lib, lib.prf_scan(ctx._h, arr, len(entries), kmin, kmax, min_repeats, min_span, SCAN_DEFAULT, ctypes.byref(hits),
+                             ctypes.byref(stats)))
+    try:
+        names = (ctypes.c_char_p * max(1, len(entries)))(*[e.name.encode() for e in entries])
+        written = ctypes.c_uint64(0)
+        _check(lib, lib.prf_write_bed(os.fsencode(bed_path), 0, names, arr, len(entries), ctypes.byref(hits), ctypes.byref(written)))
+        import numpy as np
+        counts = np.bincount(_rows(hits)["contig"], minlength=len(entries)) if hits.n else np.zeros(len(entries), dtype=np.int64)
+    finally:
+        lib.prf_free_hits(ctypes.byref(hits))
+    if on_contig:
+        for e, c in zip(entries, counts):
+            on_contig(e, int(c))
+    return [int(c) for c in counts], stats
 
 
 def plan_describe(kmin, kmax, min_repeats, min_span):

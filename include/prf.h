@@ -120,6 +120,23 @@ void prf_free_hits(prf_hits *hits);
  * an RCCL gather then ships to rank 0).  *n_rows receives the row count; at most capacity_rows are copied. */
 int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, uint64_t *n_rows);
 
+/* ---- the data formats either side of the path (host code, no GPU) ------------------------------------------
+ * FASTA reader: what the reference takes from pyfastx.Fasta (perfect_repeat_finder.py:117,130,136-143): entries in
+ * file order, name = header up to the first white space, sequence = the record's lines joined (case kept).
+ * Plain or gzip-compressed files. */
+typedef struct prf_fasta prf_fasta;
+int prf_fasta_open(const char *path, prf_fasta **out);
+int prf_fasta_count(const prf_fasta *f);
+int prf_fasta_entry(const prf_fasta *f, int i, const char **name, const uint8_t **seq, uint64_t *len);
+void prf_fasta_close(prf_fasta *f);
+
+/* Row writers: the reference's BED lines "chrom\tstart\tend\tmotif\n" (:148-149; names[i] / contigs[i] belong to
+ * hit.contig == i) and its TSV file with the header "start_0based\tend\tmotif" (:166-170).  The motif is
+ * seq.upper()[start:start+k], taken from the contig bytes. */
+int prf_write_bed(const char *path, int append, const char *const *names, const prf_contig *contigs, int n_contigs,
+                  const prf_hits *hits, uint64_t *n_written);
+int prf_write_tsv(const char *path, const prf_contig *contig, const prf_hits *hits, uint64_t *n_written);
+
 /* Host-only: describe, as one line of JSON, how a scan with these parameters is dealt to the waves of the fused
  * kernel (tasks, motif sizes, examined-group strides) or that the generic kernel is used.  Needs no GPU; used by
  * the CPU tests to check that every motif size is covered exactly once and that the sampling strides are legal.

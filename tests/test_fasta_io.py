@@ -1,0 +1,89 @@
+"""CPU: the host-side data formats of libprf -- FASTA reader (plain / gzip, CRLF, long lines, empty records, lower
+case, text before the first header) and the BED / TSV row writers -- against plain Python and the oracle."""
+import ctypes
+import gzip
+import os
+
+import numpy as np
+
+import prf_native
+from oracle import prf_oracle
+
+
+def make_fasta(path, records, gz=False, crlf=False, width=60):
+    nl = "\r\n" if crlf else "\n"
+    text = "; a comment line before the first record" + nl
+    for name, desc, seq in records:
+        text += f">{name}{desc}{nl}"
+        for i in range(0, len(seq), width):
+            text += seq[i:i + width] + nl
+        if not seq:
+            text += nl
+    opener = gzip.open if gz else open
+    with opener(path, "wt", newline="") as f:
+        f.write(text)
+
+
+RECORDS = [("chr1", " first record", "ACGTNacgtn" * 37 + "CAG" * 40),
+           ("empty", "", ""),
+           ("chr_2", "\tdescription with tab", "TTTTTTTTTTTTGACCA" * 500),
+           ("scaffold|3", " x", "N" * 200 + "AC" * 300 + "g" * 33)]
+
+
+def test_reader_matches_python(tmp_path):
+    for gz, crlf, width in ((False, False, 60), (True, False, 70), (False, True, 61), (True, True, 100000)):
+        path = str(tmp_path / f"t_{gz}_{crlf}_{width}.fa")
+        make_fasta(path, RECORDS, gz=gz, crlf=crlf, width=width)
+        fa = prf_native.Fasta(path)
+        assert [e.name for e in fa] == [r[0] for r in RECORDS]
+        assert [e.seq for e in fa] == [r[2] for r in RECORDS]
+        assert "chr_2" in fa and "nope" not in fa and fa["scaffold|3"].length == len(RECORDS[3][2])
+        fa.close()
+    # a header that is the last line, without newline
+    path = str(tmp_path / "tail.fa")
+    open(path, "w").write(">a\nACGT\n>b")
+    fa = prf_native.Fasta(path)
+    assert [(e.name, e.seq) for e in fa] == [("a", "ACGT"), ("b", "")]
+
+
+def test_missing_file_is_an_error():
+    try:
+        prf_native.Fasta("/nonexistent/file.fa")
+    except prf_native.PrfError as exc:
+        assert exc.code == prf_native.PRF_EINVAL
+    else:
+        raise AssertionError("expected PrfError")
+
+
+def test_bed_and_tsv_writers_match_the_reference_format(tmp_path):
+    lib = prf_native.load_library()
+    seqs = [r[2].encode() for r in RECORDS]
+    names = [r[0] for r in RECORDS]
+    rows = []
+    want = ""
+    for ci, s in enumerate(seqs):
+        for a, b, _ml, k in prf_oracle.detect_rows(s, 1, 20, 3, 9):
+            rows.append((a, b, k, ci))
+            want += f"{names[ci]}\t{a}\t{b}\t{s[a:a + k].decode().upper()}\n"
+    assert len(rows) > 5
+    arr = (prf_native._Hit * len(rows))(*[prf_native._Hit(*r) for r in rows])
+    hits = prf_native._Hits(arr, len(rows))
+    contigs, keep = prf_native._contig_array(seqs)
+    cnames = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    n = ctypes.c_uint64()
+    bed = str(tmp_path / "out.bed")
+    assert lib.prf_write_bed(bed.encode(), 0, cnames, contigs, len(seqs), ctypes.byref(hits), ctypes.byref(n)) == 0
+    assert n.value == len(rows) and open(bed).read() == want
+    assert lib.prf_write_bed(bed.encode(), 1, cnames, contigs, len(seqs), ctypes.byref(hits), None) == 0
+    assert open(bed).read() == want + want
+    # TSV of one contig
+    r0 = [r for r in rows if r[3] == 0]
+    arr0 = (prf_native._Hit * len(r0))(*[prf_native._Hit(a, b, k, 0) for a, b, k, _c in r0])
+    hits0 = prf_native._Hits(arr0, len(r0))
+    tsv = str(tmp_path / "out.tsv")
+    assert lib.prf_write_tsv(tsv.encode(), contigs, ctypes.byref(hits0), None) == 0
+    assert open(tsv).read() == "start_0based\tend\tmotif\n" + "".join(
+        f"{a}\t{b}\t{seqs[0][a:a + k].decode().upper()}\n" for a, b, k, _c in r0)
+    # a row that does not fit its contig is refused
+    bad = (prf_native._Hit * 1)(prf_native._Hit(10, 20, 5, 1))   # contig 1 is empty
+    assert lib.prf_write_bed(bed.encode(), 0, cnames, contigs, len(seqs), ctypes.byref(prf_native._Hits(bad, 1)), None) == prf_native.PRF_EINVAL

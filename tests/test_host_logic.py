@@ -35,9 +35,21 @@ def closed_form_rows(seq, fs, context=None):
     return sorted(rows)
 
 
+def cpu_scan_whole_fasta(fasta, bed_path, fs, report):
+    """CPU stand-in for the one-scan whole-FASTA path (which needs a GPU): per contig, closed form, Python writer."""
+    plain = argparse.Namespace(min_motif_size=fs.min_motif_size, max_motif_size=fs.max_motif_size,
+                               min_repeats=fs.min_repeats, min_span=fs.min_span)
+    with open(bed_path, "wt") as bed:
+        for entry in fasta:
+            rows = prf.detect_repeats(entry.seq, plain)
+            bed.writelines(f"{entry.name}\t{s}\t{e}\t{m}\n" for s, e, m in rows)
+            report(entry, len(rows))
+
+
 @pytest.fixture()
 def cpu_rows(monkeypatch):
     monkeypatch.setattr(prf, "_gpu_rows", closed_form_rows)
+    monkeypatch.setattr(prf, "_scan_whole_fasta", cpu_scan_whole_fasta)
 
 
 def test_shift_string_by():
