@@ -216,3 +216,15 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
     prf.main(["-min", "2", "-max", "6", "CACACACACACAGGGTTTTTTTTTTT"])
     assert open("repeats.tsv").read() == "start_0based\tend\tmotif\n0\t12\tCA\n"
     assert "Found 1 repeats" in capsys.readouterr().out
+
+
+def test_randomised_differential_stress():
+    """tools/stress_gpu.py for ~25 s: random multi-contig inputs x random parameter sets, GPU rows == oracle rows
+    (a 240 s run of the same script covered 3 924 scans without a mismatch in round 1)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_gpu.py"), "25", "11"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
