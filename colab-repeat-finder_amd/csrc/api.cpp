@@ -73,13 +73,11 @@ struct prf_ctx {
     // fused (bit-sliced) path scratch: one row slab per tile
     prf_hit_dev *d_hit_slabs = nullptr;
     u32 *d_hit_counts = nullptr;
-    u64 *d_offsets = nullptr;
     u64 slab_tiles = 0;
     u32 slab_cap = 0;
     u64 slab_serial = 0;  // genome whose tile list the slab counts currently reflect
     // where the rows of the last scan are
     u64 last_nhits = 0;
-    bool last_in_slabs = false;
 };
 
 struct prf_genome {
@@ -149,7 +147,6 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_hit_slabs);
     (void)hipFree(c->d_hit_counts);
-    (void)hipFree(c->d_offsets);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -294,15 +291,12 @@ static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap, u64 serial) {
     if (ntiles > c->slab_tiles || cap > c->slab_cap) {
         (void)hipFree(c->d_hit_slabs);
         (void)hipFree(c->d_hit_counts);
-        (void)hipFree(c->d_offsets);
         c->d_hit_slabs = nullptr;
         c->d_hit_counts = nullptr;
-        c->d_offsets = nullptr;
         c->slab_tiles = 0;
         c->slab_cap = 0;
         HIPCHK(hipMalloc((void **)&c->d_hit_slabs, ntiles * (u64)cap * sizeof(prf_hit_dev)));
         HIPCHK(hipMalloc((void **)&c->d_hit_counts, ntiles * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->d_offsets, (ntiles + 1) * sizeof(u64)));
         {
             const u64 ng = (ntiles + 63) / 64;
             (void)hipFree(c->d_group_sums);
@@ -414,9 +408,8 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             }
 #endif
             if (getenv("PRF_DEBUG"))
-                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu rec_ovf_tiles %llu hit_ovf %llu ms %.4f\n",
-                        (unsigned long long)nhits, (unsigned long long)ncand,
-                        (unsigned long long)c->h_counters[PRF_CNT_REC_OVF], (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
+                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu hit_ovf %llu ms %.4f\n", (unsigned long long)nhits,
+                        (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
             if (!again && nhits > c->hit_cap) {  // the compact array was too small: grow it and gather again
@@ -429,7 +422,6 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                                                c->d_hits, c->hit_cap, cur_counters, c->h_counters_dev, nxt_counters, nxt_groups));
                 HIPCHK(hipStreamSynchronize(c->stream));
             }
-            c->last_in_slabs = false;
         } else {
             // ---- generic path: candidates, then rows ----
             int rc = ensure_buffers(c, want_cand, want_hits);
@@ -451,7 +443,6 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             nhits = c->h_counters[PRF_CNT_HITS];
             if (ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
             if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
-            if (!again) c->last_in_slabs = false;
         }
         if (!again) break;
     }

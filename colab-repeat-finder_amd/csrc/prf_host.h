@@ -9,7 +9,6 @@ enum {
     PRF_CNT_CAND = 0,     // generic path: phase-1 candidates
     PRF_CNT_HITS = 1,     // generic path: rows
     PRF_CNT_BADPOS = 2,   // packer: first unsupported symbol
-    PRF_CNT_REC_OVF = 3,  // fused path: tiles whose LDS candidate list overflowed
     PRF_CNT_HIT_OVF = 4,  // fused path: largest per-tile row demand above the slab capacity
     PRF_CNT_SHARD0 = 8,   // fused path: per-shard sums, one 64-byte line per shard
     PRF_CNT_NSHARD = 16,
