@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--cpu-sample-bp", type=int, default=12_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel")
+    ap.add_argument("--workload", choices=["chr22", "random"], default="chr22",
+                    help="chr22: the default stand-in contig (BASELINE config C2, the headline); random: uniform ACGT "
+                         "generated on the device (config C5 is --workload random --length 1250000000 --kmax 100)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,10 +110,13 @@ def main():
 
     length = args.length or synth.CHR22_LEN
     n_head = 10_510_000 if length >= 20_000_000 else length // 10
-    seq = synth.chr_standin(length=length, seed=22 + rank, n_head=n_head, n_tail=min(10_000, length // 100)).tobytes()
-
     ctx = prf_native.Context(dev_index)
-    genome = ctx.load([seq], args.kmax)
+    if args.workload == "random":
+        genome = ctx.synth([length], [22 + rank], args.kmax)        # generated in HBM, nothing crosses PCIe
+        seq = None
+    else:
+        seq = synth.chr_standin(length=length, seed=22 + rank, n_head=n_head, n_tail=min(10_000, length // 100)).tobytes()
+        genome = ctx.load([seq], args.kmax)
     flags = prf_native.SCAN_FORCE_GENERIC if args.generic else prf_native.SCAN_DEFAULT
     scan = lambda fetch: genome.scan(args.kmin, args.kmax, args.min_repeats, args.min_span, flags=flags, fetch=fetch)
 
@@ -193,12 +199,14 @@ def main():
         achieved = bytes_alg / (p1 * 1e-3) / 1e9
         hbm_meas = ctx.measure_hbm_read(1 << 30, 5)
         out = {
-            "metric": "Gbp/s scanned (motif 1-50)", "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world,
+            "metric": f"Gbp/s scanned (motif {args.kmin}-{args.kmax})", "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 bitplanes (2-bit bases)",
             "data": "synthetic",
-            "config": {"workload": f"chr22-sized synthetic stand-in contig per GPU ({length} bp; hg38-like N blocks, "
-                                   f"planted repeats), motif {args.kmin}-{args.kmax}, min_repeats {args.min_repeats}, "
+            "config": {"workload": (f"chr22-sized synthetic stand-in contig per GPU ({length} bp; hg38-like N blocks, "
+                                    "planted repeats)" if args.workload == "chr22" else
+                                    f"uniform random ACGT contig per GPU ({length} bp, generated on the device)") +
+                                   f", motif {args.kmin}-{args.kmax}, min_repeats {args.min_repeats}, "
                                    f"min_span {args.min_span}; genome packed + resident in HBM before the timed region",
                        "kernel_path": "generic" if st0.path == 0 else "vertical",
                        "rows_per_gpu": n_rows_local, "rows_total": n_rows_total,
@@ -216,6 +224,9 @@ def main():
                           "total": round(float(np.mean(scan_ms)), 5)},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N=1 only
+            if seq is None:
+                from oracle import prf_oracle
+                seq = prf_oracle.synth(min(length, args.cpu_sample_bp), 22 + rank)
             out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,
                                                args.cpu_sample_bp)
         print(json.dumps(out), flush=True)

@@ -170,7 +170,9 @@ void prf_genome_free(prf_genome *g) {
 
 uint64_t prf_genome_positions(const prf_genome *g) { return g ? g->positions : 0; }
 
-static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out) {
+// contigs[i].ascii == nullptr with seeds != nullptr: contig i is generated on the device from seeds[i]
+static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out,
+                            const uint64_t *seeds = nullptr) {
     if (!c || !out || n_contigs < 0 || (n_contigs > 0 && !contigs))
         return fail(PRF_EINVAL, "prf_genome_load: bad arguments");
     *out = nullptr;
@@ -190,7 +192,7 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     const u64 gap = (u64)kmax_hint + 64;
     u64 cur = 0;
     for (int i = 0; i < n_contigs; i++) {
-        if (contigs[i].len && !contigs[i].ascii) return fail(PRF_EINVAL, "prf_genome_load: contig %d has NULL data", i);
+        if (contigs[i].len && !contigs[i].ascii && !seeds) return fail(PRF_EINVAL, "prf_genome_load: contig %d has NULL data", i);
         g->base.push_back(cur);
         g->len.push_back(contigs[i].len);
         g->positions += contigs[i].len;
@@ -209,9 +211,13 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
         ~asc_guard_t() { (void)hipFree(p); }
     } asc_guard{asc};
     HIPCHK(prf_launch_fill_u64(c->stream, (u64 *)asc, g->G / 8, 0x4E4E4E4E4E4E4E4Eull));  // 'N' everywhere
-    for (int i = 0; i < n_contigs; i++)
-        if (contigs[i].len)
+    for (int i = 0; i < n_contigs; i++) {
+        if (!contigs[i].len) continue;
+        if (seeds)  // the generator writes whole 16-byte groups; the tail beyond len is 'N' again, like the gap
+            HIPCHK(prf_launch_synth(c->stream, asc + g->base[i], contigs[i].len, seeds[i]));
+        else
             HIPCHK(hipMemcpyAsync(asc + g->base[i], contigs[i].ascii, contigs[i].len, hipMemcpyHostToDevice, c->stream));
+    }
     const u64 tot = PRF_FRONT_PAD + g->nwords + g->padw;
     {
         u64 *p = nullptr;
@@ -261,6 +267,19 @@ int prf_genome_load(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32
         return fail(PRF_ENOMEM, "prf_genome_load: out of host memory");
     } catch (...) {
         return fail(PRF_EHIP, "prf_genome_load: unexpected exception");
+    }
+}
+
+int prf_genome_synth(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, int n_contigs, uint32_t kmax_hint, prf_genome **out) {
+    if (n_contigs < 0 || (n_contigs > 0 && (!lens || !seeds))) return fail(PRF_EINVAL, "prf_genome_synth: bad arguments");
+    try {
+        std::vector<prf_contig> cs((size_t)(n_contigs > 0 ? n_contigs : 1));
+        for (int i = 0; i < n_contigs; i++) cs[i] = prf_contig{nullptr, lens[i]};
+        return genome_load_impl(c, cs.data(), n_contigs, kmax_hint, out, seeds);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_genome_synth: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_genome_synth: unexpected exception");
     }
 }
 

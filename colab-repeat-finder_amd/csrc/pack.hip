@@ -50,6 +50,32 @@ __global__ void prf_fill_u64_kernel(u64 *__restrict__ p, u64 n, u64 v) {
     for (; i < n; i += stride) p[i] = v;
 }
 
+// SURVEY 8(d) counter-based generator, 16 bases per lane (one 16-byte store)
+__global__ __launch_bounds__(256) void prf_synth_kernel(uint8_t *__restrict__ asc, u64 n, u64 seed) {
+    const u64 chunk = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 j0 = chunk * 16;
+    if (j0 >= n) return;
+    u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        u64 z = seed + (j0 + (u64)i + 1ull) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const u32 code = (u32)(z >> 62);
+        const u32 ch = (0x54474341u >> (8 * code)) & 0xFFu;  // "ACGT"[code]
+        w[i >> 2] |= (j0 + (u64)i < n ? ch : (u32)'N') << (8 * (i & 3));
+    }
+    *reinterpret_cast<uint4 *>(asc + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed) {
+    if (n == 0) return hipSuccess;
+    const u64 chunks = (n + 15) / 16;
+    hipLaunchKernelGGL(prf_synth_kernel, dim3((u32)((chunks + 255) / 256)), dim3(256), 0, s, asc, n, seed);
+    return hipGetLastError();
+}
+
 hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
                                   u64 *bad_pos) {
     const u32 bs = 256;

@@ -21,6 +21,7 @@ enum {
 hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
                                   u64 *bad_pos);
 hipError_t prf_launch_fill_u64(hipStream_t s, u64 *p, u64 n, u64 v);
+hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed);
 
 hipError_t prf_launch_scan_generic(hipStream_t s, const prf_planes &pl, u64 w_begin, u64 w_end, u32 kmin, u32 kmax,
                                    u32 min_repeats, u32 min_span, u64 *cand, u64 cand_cap, u64 *counters);

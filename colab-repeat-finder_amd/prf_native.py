@@ -55,7 +55,7 @@ class ScanStats(ctypes.Structure):
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
-           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv"]
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -79,6 +79,8 @@ def load_library():
         lib.prf_close.argtypes = [vp]
         lib.prf_close.restype = None
         lib.prf_genome_load.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(vp)]
+        lib.prf_genome_synth.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
+                                         ctypes.c_uint32, ctypes.POINTER(vp)]
         lib.prf_genome_free.argtypes = [vp]
         lib.prf_genome_free.restype = None
         lib.prf_genome_positions.argtypes = [vp]
@@ -195,6 +197,15 @@ class Context:
         g = ctypes.c_void_p()
         _check(self.lib, self.lib.prf_genome_load(self._h, arr, len(seqs), kmax_hint, ctypes.byref(g)))
         return Genome(self, g, len(seqs))
+
+    def synth(self, lens, seeds, kmax_hint):
+        """Contigs generated on the device (SURVEY 8(d) generator): nothing crosses PCIe."""
+        n = len(lens)
+        la = (ctypes.c_uint64 * max(1, n))(*lens)
+        sa = (ctypes.c_uint64 * max(1, n))(*seeds)
+        g = ctypes.c_void_p()
+        _check(self.lib, self.lib.prf_genome_synth(self._h, la, sa, n, kmax_hint, ctypes.byref(g)))
+        return Genome(self, g, n)
 
     def scan(self, seqs, kmin, kmax, min_repeats, min_span, flags=SCAN_DEFAULT):
         arr, _keep = _contig_array(seqs)

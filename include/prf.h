@@ -99,6 +99,11 @@ void prf_close(prf_ctx *ctx);
  * Replaces input_sequence.upper() and the three transient copies of reference :33-46.
  * kmax_hint: largest motif size later scans will use (sizes the inter-contig guard gap). */
 int prf_genome_load(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out);
+/* The same, with the contigs generated ON the device (BASELINE config C5: 10^10 bp never cross PCIe):
+ * contig i is lens[i] bases of the counter-based generator of SURVEY 8(d) with seed seeds[i],
+ * base j = "ACGT"[splitmix64(seed + (j+1)*0x9E3779B97F4A7C15) >> 62]. */
+int prf_genome_synth(prf_ctx *ctx, const uint64_t *lens, const uint64_t *seeds, int n_contigs, uint32_t kmax_hint,
+                     prf_genome **out);
 void prf_genome_free(prf_genome *g);
 uint64_t prf_genome_positions(const prf_genome *g);
 

@@ -194,6 +194,57 @@ def test_full_size_chr22_standin_vs_oracle(ctx):
     assert got == want
 
 
+def test_device_generated_contigs_equal_the_oracle_generator(ctx):
+    """prf_genome_synth writes the SURVEY 8(d) generator's bases on the device: the rows of a generated genome
+    equal the oracle's rows on the oracle's own generator output (two contigs, lengths that are not multiples
+    of the 16-base store, different seeds)."""
+    from oracle import prf_oracle
+    lens, seeds = [333_337, 70_001], [99, 12345678901234567]
+    g = ctx.synth(lens, seeds, 100)
+    try:
+        assert g.positions == sum(lens)
+        rows, stats = g.scan(1, 100, 3, 9)
+        assert stats.path == 1
+        want = [(c, s, e, k) for c, (n, sd) in enumerate(zip(lens, seeds))
+                for s, e, _m, k in prf_oracle.detect_rows(prf_oracle.synth(n, sd), 1, 100, 3, 9)]
+        assert rows_as_tuples(rows) == want and len(want) > 100
+    finally:
+        g.free()
+
+
+def test_config_c5_share_random_1250mbp_motif_1_100(ctx):
+    """BASELINE config C5, one GPU's share (10 Gbp / 8 = 1.25 Gbp of random ACGT generated on the device,
+    motif 1-100).  Too long for the oracle as a whole, so: (1) size-independent properties of the row set,
+    (2) the fused and the generic kernel -- independent implementations -- agree row for row, (3) on three
+    2 Mbp windows the oracle's rows that lie strictly inside the window equal the GPU's rows there (a maximal
+    run strictly inside a window is maximal in the whole contig)."""
+    import prf_native
+    from oracle import prf_oracle
+    n, seed = 1_250_000_000, 5
+    g = ctx.synth([n], [seed], 100)
+    try:
+        rows, stats = g.scan(1, 100, 3, 9)
+        assert stats.path == 1 and stats.positions == n
+        starts = rows["start"].astype(np.int64)
+        ends = rows["end"].astype(np.int64)
+        ks = rows["k"].astype(np.int64)
+        assert len(rows) > 200_000
+        assert np.all((starts[1:] > starts[:-1]) | ((starts[1:] == starts[:-1]) & (ends[1:] > ends[:-1])))
+        assert np.all(ends - starts >= np.maximum(3 * ks, 9)) and ends.max() <= n and ks.max() <= 100
+        rows2, stats2 = g.scan(1, 100, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert stats2.path == 0 and np.array_equal(rows, rows2)
+        win, margin = 2_000_000, 1_000
+        for off in (0, 617_283_951, n - win):
+            chunk = prf_oracle.synth(win, seed, start=off)
+            want = [(s + off, e + off, k) for s, e, _m, k in prf_oracle.detect_rows(chunk, 1, 100, 3, 9)
+                    if s >= margin and e <= win - margin]
+            sel = (starts >= off + margin) & (ends <= off + win - margin)
+            got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
+            assert got == want and len(want) > 300, off
+    finally:
+        g.free()
+
+
 def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
     """The drop-in command line end to end on the GPU: multi-contig FASTA -> BED, literal sequence -> TSV."""
     import argparse
