@@ -62,8 +62,6 @@ struct prf_ctx {
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
-    u32 *d_group_sums = nullptr; // fused path: two arrays of per-64-slab row totals, used alternately
-    u64 group_cap = 0;
     u32 parity = 0;
     // generic path scratch
     u64 *d_cand = nullptr;
@@ -72,10 +70,8 @@ struct prf_ctx {
     u64 hit_cap = 0;
     // fused (bit-sliced) path scratch: one row slab per tile
     prf_hit_dev *d_hit_slabs = nullptr;
-    u32 *d_hit_counts = nullptr;
     u64 slab_tiles = 0;
     u32 slab_cap = 0;
-    u64 slab_serial = 0;  // genome whose tile list the slab counts currently reflect
     // where the rows of the last scan are
     u64 last_nhits = 0;
 };
@@ -142,11 +138,9 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_counters);
     (void)hipHostFree(c->h_counters);
     (void)hipFree(c->d_vcounters);
-    (void)hipFree(c->d_group_sums);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_hit_slabs);
-    (void)hipFree(c->d_hit_counts);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -301,34 +295,15 @@ static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
     return PRF_OK;
 }
 
-static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap, u64 serial) {
-    if (ntiles <= c->slab_tiles && cap <= c->slab_cap && serial != c->slab_serial) {
-        // another genome: tiles that are never launched (nothing but N) must read as empty
-        HIPCHK(hipMemsetAsync(c->d_hit_counts, 0, c->slab_tiles * sizeof(u32), c->stream));
-        c->slab_serial = serial;
-    }
+static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap) {
     if (ntiles > c->slab_tiles || cap > c->slab_cap) {
         (void)hipFree(c->d_hit_slabs);
-        (void)hipFree(c->d_hit_counts);
         c->d_hit_slabs = nullptr;
-        c->d_hit_counts = nullptr;
         c->slab_tiles = 0;
         c->slab_cap = 0;
         HIPCHK(hipMalloc((void **)&c->d_hit_slabs, ntiles * (u64)cap * sizeof(prf_hit_dev)));
-        HIPCHK(hipMalloc((void **)&c->d_hit_counts, ntiles * sizeof(u32)));
-        {
-            const u64 ng = (ntiles + 63) / 64;
-            (void)hipFree(c->d_group_sums);
-            c->d_group_sums = nullptr;
-            HIPCHK(hipMalloc((void **)&c->d_group_sums, 2 * ng * sizeof(u32)));
-            HIPCHK(hipMemsetAsync(c->d_group_sums, 0, 2 * ng * sizeof(u32), c->stream));
-            c->group_cap = ng;
-        }
-        // tiles that are never launched (nothing but N) must read as empty
-        HIPCHK(hipMemsetAsync(c->d_hit_counts, 0, ntiles * sizeof(u32), c->stream));
         c->slab_tiles = ntiles;
         c->slab_cap = cap;
-        c->slab_serial = serial;
     }
     return PRF_OK;
 }
@@ -367,7 +342,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         if (vs) {
             // ---- fused bit-sliced kernel: scan + verify + rows in one launch ----
             const u64 nslabs = ntiles * 4;  // a tile with N in reach is scanned by 4 workgroups, each with its own slab
-            int rc = ensure_slabs(c, nslabs, slab_cap, g->serial);
+            int rc = ensure_slabs(c, nslabs, slab_cap);
             if (rc) return rc;
             prf_vscan_args &a = va;
             a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
@@ -375,16 +350,18 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.tile_list = g->vp.tile_list;
             a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
             a.clean_base = g->vp.clean_base;
-            a.hit_slabs = c->d_hit_slabs; a.hit_counts = c->d_hit_counts; a.hit_cap = c->slab_cap;
+            a.hit_slabs = c->d_hit_slabs; a.hit_cap = c->slab_cap;
             a.min_repeats = min_repeats; a.min_span = min_span;
             a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
-            u64 *cur_counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
-            u64 *nxt_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
-            u32 *cur_groups = c->d_group_sums + (size_t)c->parity * c->group_cap;
-            u32 *nxt_groups = c->d_group_sums + (size_t)(c->parity ^ 1u) * c->group_cap;
+            if (a.n_clean + a.n_mixed == 0) {  // nothing but N (or no contig at all): no tile to launch, no rows
+                nhits = ncand = 0;
+                launches = 0;
+                break;
+            }
+            a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
+            a.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
+            a.host_counters = c->h_counters_dev;
             c->parity ^= 1u;
-            a.counters = cur_counters;
-            a.group_sums = cur_groups;
             a.dbg = nullptr;
 #ifdef PRF_STAMPS
             static u64 *dbg_buf = nullptr;
@@ -393,24 +370,20 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
 #endif
             rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
             if (rc) return rc;
-            // three calls into the runtime per scan: two kernels and one synchronise (+ event records); the counter
-            // block for this scan was cleared on the device by the previous scan's compaction kernel
+            a.rows = c->d_hits; a.rows_cap = c->hit_cap;
+            // ONE kernel per scan: it also compacts the rows (a reservation per workgroup in the row array), hands
+            // the counters to the host through mapped memory and clears the counter block of the next scan
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
             HIPCHK(prf_vertical_launch(c->stream, a));
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
-            // rows of the per-tile slabs -> one compact array; counters -> mapped host memory
-            HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, nslabs, cur_groups,
-                                           c->d_hits, c->hit_cap, cur_counters, c->h_counters_dev, nxt_counters, nxt_groups));
-            HIPCHK(hipEventRecord(c->ev[2], c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
-            HIPCHK(hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]));
-            launches = 2;
-            ncand = nhits = 0;
-            for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) {
-                nhits += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_HITS];
+            ms12 = 0;
+            launches = 1;
+            nhits = c->h_counters[PRF_CNT_ROWS] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+            ncand = 0;
+            for (int sh = 0; sh < PRF_CNT_NSHARD; sh++)
                 ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
-            }
 #ifdef PRF_STAMPS
             if (getenv("PRF_STAMPS_OUT")) {
                 fprintf(stderr, "[prf] plan: %u waves, %u tasks\n", a.plan.n_waves, a.plan.n_tasks);
@@ -431,15 +404,9 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                         (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
-            if (!again && nhits > c->hit_cap) {  // the compact array was too small: grow it and gather again
+            if (!again && nhits > c->hit_cap) {  // the compact row array was too small: grow it and scan again
                 want_hits = nhits + nhits / 8 + 1024;
-                rc = ensure_buffers(c, c->cand_cap, want_hits);
-                if (rc) return rc;
-                // (the counters were already cleared for the next scan: gather with the same group sums, and clear
-                // the same "next" arrays again, which is harmless)
-                HIPCHK(prf_launch_compact_hits(c->stream, c->d_hit_slabs, c->d_hit_counts, c->slab_cap, nslabs, cur_groups,
-                                               c->d_hits, c->hit_cap, cur_counters, c->h_counters_dev, nxt_counters, nxt_groups));
-                HIPCHK(hipStreamSynchronize(c->stream));
+                again = true;
             }
         } else {
             // ---- generic path: candidates, then rows ----

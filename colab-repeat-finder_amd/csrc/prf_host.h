@@ -5,11 +5,15 @@
 #include "prf_device.h"
 
 // device counter block (u64 each)
+#define PRF_ROWS_TICKET_SHIFT 40
+
 enum {
     PRF_CNT_CAND = 0,     // generic path: phase-1 candidates
     PRF_CNT_HITS = 1,     // generic path: rows
     PRF_CNT_BADPOS = 2,   // packer: first unsupported symbol
     PRF_CNT_HIT_OVF = 4,  // fused path: largest per-tile row demand above the slab capacity
+    PRF_CNT_ROWS = 5,     // fused path: [39:0] cursor of the compact row array, [63:40] workgroups finished (one
+                          // atomic per workgroup does both; the last workgroup hands the counters to the host)
     PRF_CNT_SHARD0 = 8,   // fused path: per-shard sums, one 64-byte line per shard
     PRF_CNT_NSHARD = 16,
     PRF_CNT_SHARD_STRIDE = 8,

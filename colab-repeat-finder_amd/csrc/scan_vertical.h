@@ -46,13 +46,15 @@ struct prf_vscan_args {
     u32 n_clean, n_mixed;
     u32 clean_base;                // first clean tile if the clean tiles are one contiguous range, else ~0u
     prf_hit_dev *hit_slabs;        // [tile*4 + part][hit_cap]  (clean tiles use part 0 only)
-    u32 *hit_counts;               // [tile*4 + part]
-    u32 *group_sums;               // [(tile*4 + part) / 64]: rows per 64 slabs (zero when the kernel starts)
     u32 hit_cap;
+    prf_hit_dev *rows;             // the compact row array: every workgroup reserves its range with one atomic
+    u64 rows_cap;
     u32 min_repeats, min_span;
     const u64 *contig_base;
     u32 n_contigs;
-    u64 *counters;
+    u64 *counters;                 // this scan's counter block (zero when the kernel starts)
+    u64 *host_counters;            // mapped host memory: the last workgroup copies the counter block there ...
+    u64 *next_counters;            // ... and clears the block the next scan will use
     u64 *dbg;                      // diagnostic (PRF_STAMPS) builds only; nullptr otherwise
     prf_vplan plan;
 };
@@ -65,8 +67,3 @@ int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp)
 
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args);
 
-// rows of the per-tile slabs -> one compact array in slab order; also copies the scan's counter block to mapped
-// host memory and clears the counter block / group sums the NEXT scan will use (see scan_vertical.hip)
-hipError_t prf_launch_compact_hits(hipStream_t s, const prf_hit_dev *hit_slabs, const u32 *hit_counts, u32 hit_cap,
-                                   u64 nslabs, const u32 *group_sums, prf_hit_dev *out, u64 out_cap, const u64 *counters,
-                                   u64 *host_counters, u64 *next_counters, u32 *next_group_sums);

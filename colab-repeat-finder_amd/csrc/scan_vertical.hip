@@ -640,17 +640,45 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     for (int w = 0; w < MAX_WAVES; w++) total += rec_cnt[w];
     const u32 n_records = em.handled + verify_records((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);
     PRF_STAMP(5);
+    if (n_records)
+        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_records);
     __syncthreads();
     PRF_STAMP(6);
-    u64 *sh = g.counters + PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE;
-    if (n_records) atomicAdd(&sh[PRF_SH_CAND], (u64)n_records);
+    // ---- 4. the tile's rows -> the compact row array: ONE atomic per workgroup reserves its range (low 40 bits:
+    // row cursor) and draws its finishing ticket (high 24 bits), then the slab (written by this workgroup, still in
+    // this CU's L1/L2) is copied there.  The order of the ranges is whatever order the workgroups get here in; the
+    // host sorts rows after the fetch anyway (reference perfect_repeat_finder.py:81).
+    u64 *xch = reinterpret_cast<u64 *>(recs);  // the candidate lists are dead now
     if (tid == 0) {
         const u32 n = *hit_cnt;
         const u32 stored = n < g.hit_cap ? n : g.hit_cap;
-        g.hit_counts[tile * 4 + part] = stored;
-        if (stored) atomicAdd(&g.group_sums[(tile * 4 + part) >> 6], stored);  // rows per 64 slabs, for the compaction
-        atomicAdd(&sh[PRF_SH_HITS], (u64)n);
-        if (n > g.hit_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
+        if (n > g.hit_cap) {  // rare: wait for the result, so that the maximum is in place before the ticket is drawn
+            const u64 prev = atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
+            asm volatile("" ::"v"(prev));
+        }
+        xch[0] = atomicAdd(&g.counters[PRF_CNT_ROWS], (u64)stored | (1ull << PRF_ROWS_TICKET_SHIFT));
+        xch[1] = stored;
+    }
+    __syncthreads();
+    const u64 base = xch[0] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+    const u64 ticket = xch[0] >> PRF_ROWS_TICKET_SHIFT;
+    const u32 stored = (u32)xch[1];
+    if (base + stored <= g.rows_cap) {  // else: the host sees the cursor beyond the capacity, grows the array, rescans
+        const u64 *src = reinterpret_cast<const u64 *>(g.hit_slabs + (tile * 4 + part) * (u64)g.hit_cap);
+        u64 *dst = reinterpret_cast<u64 *>(g.rows + base);
+        for (u32 i = (u32)tid; i < 3u * stored; i += (u32)nt) dst[i] = src[i];
+    }
+    // ---- 5. the last workgroup to draw a ticket hands the counter block to the host (mapped memory, no copy call)
+    // and clears the block of the next scan (no memset call).  The counters are only ever touched by device-scope
+    // atomics, performed at the coherence point; every wave's counter atomics were issued before the barrier in
+    // front of step 4, which waits for outstanding memory operations, so they precede the ticket.  (No
+    // __threadfence(): at agent scope it writes back the XCD's whole L2, once per workgroup -- measured 1.4x on
+    // the chr22 scan and 3.5x on 400 Mbp.)
+    if (ticket == (u64)gridDim.x - 1ull) {
+        for (u32 i = (u32)tid; i < (u32)PRF_CNT_N; i += (u32)nt) {
+            g.host_counters[i] = atomicAdd(&g.counters[i], 0ull);
+            g.next_counters[i] = 0;
+        }
     }
 }
 
@@ -709,68 +737,7 @@ __global__ void prf_tile_class_kernel(const unsigned char *__restrict__ any_all,
     cls[i] = (a & 2) ? 2 : (((a | b) & 1) ? 1 : 0);
 }
 
-// ---- rows of the per-tile slabs -> one compact array in slab order, ONE launch ----
-// Block g owns the 64 slabs [64g, 64g+64).  Its offset = sum of the per-group row totals of the groups before it
-// (group_sums, accumulated by the scan kernel) + an exclusive scan of its own 64 counts.  The last block also
-// hands the scan's counters to the host (mapped pinned memory: no copy call) and every block clears its share
-// of the OTHER parity's counters / group sums, which the next scan will use (no memset call).
-__global__ __launch_bounds__(256) void prf_compact_hits_kernel(const prf_hit_dev *__restrict__ slabs, const u32 *__restrict__ counts,
-                                                               u32 hit_cap, u64 nslabs, const u32 *__restrict__ group_sums,
-                                                               prf_hit_dev *__restrict__ out, u64 out_cap,
-                                                               const u64 *__restrict__ counters, u64 *__restrict__ host_counters,
-                                                               u64 *__restrict__ next_counters, u32 *__restrict__ next_group_sums,
-                                                               u32 ngroups) {
-    __shared__ u64 red[256];
-    __shared__ u64 slab_off[64];
-    const u32 g = blockIdx.x >> 3, sub = blockIdx.x & 7u, tid = threadIdx.x;  // 8 blocks per group: 8 slabs each
-    u64 before = 0;
-    for (u32 j = tid; j < g; j += 256) before += group_sums[j];
-    red[tid] = before;
-    __syncthreads();
-    for (u32 d = 128; d > 0; d >>= 1) {
-        if (tid < d) red[tid] += red[tid + d];
-        __syncthreads();
-    }
-    const u64 base = red[0];
-    if (tid < 64) {  // exclusive scan of the 64 counts by one wave
-        const u64 slab = (u64)g * 64 + tid;
-        const u32 n = slab < nslabs ? counts[slab] : 0u;
-        u32 incl = n;
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 v = __shfl_up(incl, d);
-            if ((int)tid >= d) incl += v;
-        }
-        slab_off[tid] = base + incl - n;
-    }
-    __syncthreads();
-    for (u32 sidx = sub * 8; sidx < sub * 8 + 8; sidx++) {
-        const u64 slab = (u64)g * 64 + sidx;
-        if (slab >= nslabs) break;
-        const u32 n = counts[slab];
-        const u64 off = slab_off[sidx];
-        if (n == 0 || off + n > out_cap) continue;  // too small an output array: the host sees the total and retries
-        const prf_hit_dev *src = slabs + slab * (u64)hit_cap;
-        for (u32 i = tid; i < n; i += 256) out[off + i] = src[i];
-    }
-    // housekeeping for the host and for the next scan
-    if (blockIdx.x == gridDim.x - 1) {
-        for (u32 i = tid; i < (u32)PRF_CNT_N; i += 256) host_counters[i] = counters[i];
-    }
-    for (u32 i = blockIdx.x * 256 + tid; i < (u32)PRF_CNT_N; i += gridDim.x * 256) next_counters[i] = 0;
-    for (u32 i = blockIdx.x * 256 + tid; i < ngroups; i += gridDim.x * 256) next_group_sums[i] = 0;
-}
-
 }  // namespace
-
-hipError_t prf_launch_compact_hits(hipStream_t s, const prf_hit_dev *hit_slabs, const u32 *hit_counts, u32 hit_cap,
-                                   u64 nslabs, const u32 *group_sums, prf_hit_dev *out, u64 out_cap, const u64 *counters,
-                                   u64 *host_counters, u64 *next_counters, u32 *next_group_sums) {
-    const u32 ngroups = (u32)((nslabs + 63) / 64);
-    if (ngroups == 0) return hipSuccess;
-    hipLaunchKernelGGL(prf_compact_hits_kernel, dim3(ngroups * 8), dim3(256), 0, s, hit_slabs, hit_counts, hit_cap, nslabs,
-                       group_sums, out, out_cap, counters, host_counters, next_counters, next_group_sums, ngroups);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Work plan: which wave runs which motif sizes.  Pure host code.
