@@ -58,11 +58,15 @@ struct prf_ctx {
     int dev = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // fused path: one event pair per scan, in a ring, so that the kernel times of the last PRF_TIMING_RING scans can
+    // be read after a timing loop (prf_scan_timings) instead of waiting for the events inside every scan
+    hipEvent_t ring[2 * PRF_TIMING_RING] = {};
     u64 *d_counters = nullptr;   // generic path + packer
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
     u32 parity = 0;
+    u64 scan_seq = 0;
     // generic path scratch
     u64 *d_cand = nullptr;
     u64 cand_cap = 0;
@@ -122,8 +126,9 @@ int prf_open(int device_id, prf_ctx **out) {
     c->dev = device_id;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    for (auto &ev : c->ring) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipMalloc((void **)&c->d_counters, PRF_CNT_N * sizeof(u64)));
-    HIPCHK(hipHostMalloc((void **)&c->h_counters, PRF_CNT_N * sizeof(u64), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void **)&c->h_counters, (PRF_CNT_N + 8) * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0));
     HIPCHK(hipMalloc((void **)&c->d_vcounters, 2 * PRF_CNT_N * sizeof(u64)));
     HIPCHK(hipMemset(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64)));
@@ -142,6 +147,8 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_hit_slabs);
     for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ring)
         if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -277,6 +284,38 @@ int prf_genome_synth(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, in
     }
 }
 
+// poll the serial number the fused kernel's last workgroup writes behind the counter block (mapped host memory)
+static int wait_for_seq(prf_ctx *c, u64 seq) {
+    const u64 *seqp = c->h_counters + PRF_CNT_N;
+    for (u64 spins = 1;; spins++) {
+        if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) return PRF_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0) {  // every ~millisecond: is the stream still alive?
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) return PRF_OK;
+                return fail(PRF_EHIP, "fused scan kernel finished without posting its counters");
+            }
+            if (e != hipErrorNotReady) return fail(PRF_EHIP, "fused scan kernel failed: %s", hipGetErrorString(e));
+        }
+    }
+}
+
+int prf_scan_timings(prf_ctx *c, uint64_t first_seq, uint32_t n, float *kernel_ms) {
+    if (!c || (n && !kernel_ms)) return fail(PRF_EINVAL, "prf_scan_timings: bad arguments");
+    if (first_seq == 0 || first_seq + n - 1 > c->scan_seq || c->scan_seq - first_seq >= PRF_TIMING_RING)
+        return fail(PRF_EINVAL, "prf_scan_timings: scans %llu..%llu are not among the last %d fused scans of this context",
+                    (unsigned long long)first_seq, (unsigned long long)(first_seq + n - 1), PRF_TIMING_RING);
+    HIPCHK(hipSetDevice(c->dev));
+    for (uint32_t i = 0; i < n; i++) {
+        const u64 q = first_seq + i;
+        hipEvent_t ev_a = c->ring[2 * (q % PRF_TIMING_RING)], ev_b = c->ring[2 * (q % PRF_TIMING_RING) + 1];
+        HIPCHK(hipEventSynchronize(ev_b));
+        HIPCHK(hipEventElapsedTime(&kernel_ms[i], ev_a, ev_b));
+    }
+    return PRF_OK;
+}
+
 static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
     if (want_cand > c->cand_cap) {
         (void)hipFree(c->d_cand);
@@ -361,6 +400,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
             a.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
             a.host_counters = c->h_counters_dev;
+            a.seq = ++c->scan_seq;
             c->parity ^= 1u;
             a.dbg = nullptr;
 #ifdef PRF_STAMPS
@@ -373,11 +413,20 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             a.rows = c->d_hits; a.rows_cap = c->hit_cap;
             // ONE kernel per scan: it also compacts the rows (a reservation per workgroup in the row array), hands
             // the counters to the host through mapped memory and clears the counter block of the next scan
-            HIPCHK(hipEventRecord(c->ev[0], c->stream));
+            hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
+            HIPCHK(hipEventRecord(ev_a, c->stream));
             HIPCHK(prf_vertical_launch(c->stream, a));
-            HIPCHK(hipEventRecord(c->ev[1], c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]));
+            HIPCHK(hipEventRecord(ev_b, c->stream));
+            // The scan is over for the host when the last workgroup has posted the counter block and this scan's
+            // serial number in mapped host memory: poll that word instead of waiting for the stream to drain
+            // (the kernel's end-of-grid handshake, the event and the wake-up cost ~5 us of a ~50 us chr22 scan).
+            // Everything that consumes the rows is enqueued on the same stream, hence ordered after the kernel.
+            rc = wait_for_seq(c, a.seq);
+            if (rc) return rc;
+            if (stats && !(flags & PRF_SCAN_DEFER_TIMING)) {
+                HIPCHK(hipEventSynchronize(ev_b));
+                HIPCHK(hipEventElapsedTime(&ms01, ev_a, ev_b));
+            }
             ms12 = 0;
             launches = 1;
             nhits = c->h_counters[PRF_CNT_ROWS] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
@@ -443,6 +492,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         stats->n_hits = nhits;
         stats->n_launches = launches;
         stats->path = vs ? 1 : 0;
+        stats->seq = vs ? c->scan_seq : 0;
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
     if (nhits == 0) return PRF_OK;

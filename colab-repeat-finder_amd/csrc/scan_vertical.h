@@ -54,6 +54,7 @@ struct prf_vscan_args {
     u32 n_contigs;
     u64 *counters;                 // this scan's counter block (zero when the kernel starts)
     u64 *host_counters;            // mapped host memory: the last workgroup copies the counter block there ...
+    u64 seq;                       // ... followed by this serial number at host_counters[PRF_CNT_N]
     u64 *next_counters;            // ... and clears the block the next scan will use
     u64 *dbg;                      // diagnostic (PRF_STAMPS) builds only; nullptr otherwise
     prf_vplan plan;

@@ -679,6 +679,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             g.host_counters[i] = atomicAdd(&g.counters[i], 0ull);
             g.next_counters[i] = 0;
         }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&g.host_counters[PRF_CNT_N], g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -22,6 +22,8 @@ PRF_ESYMBOL = -6
 SCAN_DEFAULT = 0
 SCAN_FORCE_GENERIC = 1
 SCAN_NO_FETCH = 2
+SCAN_DEFER_TIMING = 4
+TIMING_RING = 128
 
 
 class PrfError(RuntimeError):
@@ -46,7 +48,8 @@ class _Hits(ctypes.Structure):
 class ScanStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_double), ("phase1_ms", ctypes.c_double), ("phase2_ms", ctypes.c_double),
                 ("positions", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
-                ("n_hits", ctypes.c_uint64), ("n_launches", ctypes.c_uint32), ("path", ctypes.c_uint32)]
+                ("n_hits", ctypes.c_uint64), ("n_launches", ctypes.c_uint32), ("path", ctypes.c_uint32),
+                ("seq", ctypes.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -55,7 +58,7 @@ class ScanStats(ctypes.Structure):
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
-           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth"]
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -94,6 +97,7 @@ def load_library():
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
         lib.prf_fasta_count.argtypes = [vp]
@@ -223,6 +227,12 @@ class Context:
         n = ctypes.c_uint64(0)
         _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows, ctypes.byref(n)))
         return n.value
+
+    def scan_timings(self, first_seq, n):
+        """HIP-event kernel times (ms) of n fused scans from serial number first_seq (ScanStats.seq) on."""
+        out = (ctypes.c_float * max(1, n))()
+        _check(self.lib, self.lib.prf_scan_timings(self._h, first_seq, n, out))
+        return [float(out[i]) for i in range(n)]
 
     def measure_hbm_read(self, nbytes=1 << 30, iters=5):
         out = ctypes.c_double(0)

@@ -80,12 +80,17 @@ typedef struct prf_scan_stats {
     uint64_t n_hits;        /* rows                                                                      */
     uint32_t n_launches;    /* kernel launches in the timed region                                       */
     uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel                        */
+    uint64_t seq;           /* fused path: serial number of this scan on its context (prf_scan_timings)  */
 } prf_scan_stats;
 
 /* prf_scan flags */
 #define PRF_SCAN_DEFAULT 0u
 #define PRF_SCAN_FORCE_GENERIC 1u /* use the generic (any k, any thresholds) kernel even if a tuned one exists */
 #define PRF_SCAN_NO_FETCH 2u      /* leave rows on the device (out may be NULL); for timing loops               */
+#define PRF_SCAN_DEFER_TIMING 4u  /* fused path: do not wait for this scan's HIP events; scan_ms / phase*_ms are
+                                   * reported as 0 and read later, for up to the last PRF_TIMING_RING scans, with
+                                   * prf_scan_timings()                                                         */
+#define PRF_TIMING_RING 128
 
 int prf_abi_version(void);
 int prf_device_count(void);
@@ -117,6 +122,10 @@ int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t k
  * This is the call that replaces the body of reference detect_repeats() (:33-81). */
 int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax,
              uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
+
+/* HIP-event kernel times (ms) of the fused scans first_seq .. first_seq+n-1 of this context (prf_scan_stats.seq);
+ * they must be among its last PRF_TIMING_RING fused scans.  Waits for those scans' events. */
+int prf_scan_timings(prf_ctx *ctx, uint64_t first_seq, uint32_t n, float *kernel_ms);
 
 void prf_free_hits(prf_hits *hits);
 
