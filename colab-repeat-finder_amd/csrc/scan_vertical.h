@@ -68,3 +68,4 @@ int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp)
 
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args);
 
+

@@ -132,7 +132,7 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
     const u32 back = kind == (u32)PRF_KIND_START ? 1u : (8u << (kind - 1u));  // 1, 8, 16, 32
     const u32 before = mismatch32(h, l, p - 32u, k);  // bit 31 = position p-1
     const u32 nmatch = (u32)__builtin_clz(before | 1u);   // matches directly before p (31 if none seen: >= back then)
-    if (before == 0 || nmatch >= back) return 0;         // START: p sits inside a run; GROUP*: an earlier examined group reports
+    if (before == 0 || nmatch >= back) return 0; // START: p sits inside a run; GROUP*: an earlier examined group reports
     const u32 a = p - nmatch;
     u32 b = p;
     for (;;) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
     u32 rest = k;
 #define PRF_TRY_PRIME32(P)                                   \
     if (rest % P == 0) {                                     \
-        if (has_period32(h, l, a, k, k / P)) return 0;       \
+        if (has_period32(h, l, a, k, k / P)) return 0; \
         do rest /= P; while (rest % P == 0);                 \
     }
     if (k >= 2) {
@@ -245,6 +245,19 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
     return handled;
 }
 
+// bit t of the result: bits t .. t+M-1 of z are all ones (M <= 16)
+template <int M>
+__device__ __forceinline__ u32 ones_run(u32 z) {
+    if constexpr (M == 1) return z;
+    else {
+        constexpr int L = M >= 8 ? 8 : (M >= 4 ? 4 : 2);
+        u32 r = z & (z >> 1);
+        if constexpr (L >= 4) r &= r >> 2;
+        if constexpr (L >= 8) r &= r >> 4;
+        return r & (r >> (M - L));
+    }
+}
+
 struct Emit {
     u64 *recs;           // this wave's list in LDS, REC_PER_WAVE records
     u64 *all_recs;       // all lists
@@ -253,6 +266,49 @@ struct Emit {
     u32 handled;         // records this lane verified in early flushes
     u64 lane_pos;        // tile base + lane*32
     int lane;
+    prf_lds_cu32 *lin_h, *lin_l;  // the linear window in LDS
+    u32 win_q;           // window position of the lane's first stream: 64 + lane*32
+
+    // Exact tasks.  Like push(), plus the echo filter: a candidate at position t says that [t, t+M+k) has period
+    // k and holds no N.  If the M positions from t on ALSO all match at a shift d < k, then [t, t+M+d) has both
+    // periods, M+d >= k+d-gcd(k,d) because M >= k, so by Fine and Wilf it has period gcd(k,d) -- a proper divisor of
+    // k: the motif seq[t:t+k] is a power of a shorter word and the reference's consists_of_perfect_repeats test
+    // (utils/perfect_repeat_tracker.py:108-142) would drop the row.  Such echoes of homopolymer and dinucleotide
+    // repeats are about half of all exact candidates on genomic sequence.  The test reads 32 positions of the
+    // linear window (LDS) per record: shifts 1 and 2, all 8 rows of the record at once.
+    template <int M>
+    __device__ __forceinline__ void push_start(u32 hot, const u32 (&c)[8], int row, u32 k) {
+        while (__builtin_amdgcn_ballot_w64(hot != 0) != 0) {
+            u32 mask = 0, b = 0;
+            if (hot) {
+                b = (u32)__builtin_ctz(hot);
+                hot &= hot - 1;
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mask |= ((c[i] >> b) & 1u) << i;
+                });
+                if (k > 1) {  // wave-uniform
+                    const u32 q0 = win_q + b * (64u * T) + (u32)row;
+                    const u32 wh = look32(lin_h, q0), wl = look32(lin_l, q0);
+                    mask &= ~ones_run<M>(~((wh ^ (wh >> 1)) | (wl ^ (wl >> 1))));
+                    // (shift 2 only for even k: with k odd, periods k and 2 give period 1, which the line above caught)
+                    if (k > 2 && !(k & 1u)) mask &= ~ones_run<M>(~((wh ^ (wh >> 2)) | (wl ^ (wl >> 2))));
+                }
+            }
+            const u64 bal = __builtin_amdgcn_ballot_w64(mask != 0);
+            if (bal == 0) continue;
+            const u32 n = (u32)__builtin_popcountll(bal);
+            if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
+                handled += verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
+                cnt = 0;
+            }
+            if (mask) {
+                const u32 idx = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                recs[idx] = make_rec(lane_pos + (u64)b * (64u * T) + (u64)row, PRF_KIND_START, k, mask);
+            }
+            cnt += n;
+        }
+    }
 
     // Every lane of the wave calls this together.  `hot`: bit b set = stream (lane, b) reports for the 8-row
     // group starting at `row`; c[0..7] are the candidate words whose bit b forms the record's mask.
@@ -435,7 +491,7 @@ __device__ __forceinline__ void exact_task(const uint4 *vimg, int lane, u32 k, i
             hot |= cand[t];
         });
         mprev = m[8];
-        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, PRF_KIND_START, k);
+        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.template push_start<M>(hot, cand, 8 * tb, k);
     }
 }
 
@@ -623,6 +679,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     em.handled = 0;
     em.lane_pos = tile * PRF_TILE + (u64)lane * T;
     em.lane = lane;
+    em.lin_h = (prf_lds_cu32 *)(prf_smem + lin_off);
+    em.lin_l = em.lin_h + 2 * LW;
+    em.win_q = 64u + (u32)lane * T;
 #ifdef PRF_STAMPS
     u64 *task_dbg = g.dbg ? g.dbg + ((u64)blockIdx.x * MAX_WAVES + wave) * 16 : nullptr;
 #else
@@ -674,6 +733,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     // front of step 4, which waits for outstanding memory operations, so they precede the ticket.  (No
     // __threadfence(): at agent scope it writes back the XCD's whole L2, once per workgroup -- measured 1.4x on
     // the chr22 scan and 3.5x on 400 Mbp.)
+    PRF_STAMP(7);
     if (ticket == (u64)gridDim.x - 1ull) {
         for (u32 i = (u32)tid; i < (u32)PRF_CNT_N; i += (u32)nt) {
             g.host_counters[i] = atomicAdd(&g.counters[i], 0ull);

@@ -14,15 +14,17 @@ _, st = g.scan(1, 50, 3, 9, fetch=False)
 print('kernel ms', st.phase1_ms)
 d = np.fromfile(os.environ['PRF_STAMPS_OUT'], dtype=np.uint64).reshape(-1, 4, 16).astype(np.int64)
 t0 = d[:, :, 0].min()
-names = ['stage', 'bar1', 'scan', 'bar2', 'verify', 'bar3']
+names = ['stage', 'bar1', 'scan', 'bar2', 'verify', 'bar3', 'rows']
 for w in range(4):
-    seg = [np.median(d[:, w, i + 1] - d[:, w, i]) for i in range(6)]
-    print('wave', w, ' '.join(f'{n}={int(v)}' for n, v in zip(names, seg)), 'total', int(np.median(d[:, w, 6] - d[:, w, 0])))
+    seg = [np.median(d[:, w, i + 1] - d[:, w, i]) for i in range(7)]
+    print('wave', w, ' '.join(f'{n}={int(v)}' for n, v in zip(names, seg)), 'total', int(np.median(d[:, w, 7] - d[:, w, 0])))
 print('WG start spread (cycles): min', 0, 'median', int(np.median(d[:, 0, 0] - t0)), 'max', int((d[:, 0, 0] - t0).max()))
-print('WG end   (cycles): median', int(np.median(d[:, :, 6].max(axis=1) - t0)), 'max', int((d[:, :, 6].max(axis=1) - t0).max()))
-tot = (d[:, :, 6].max(axis=1) - d[:, :, 0].min(axis=1))
+print('WG end   (cycles): median', int(np.median(d[:, :, 7].max(axis=1) - t0)), 'max', int((d[:, :, 7].max(axis=1) - t0).max()))
+tot = (d[:, :, 7].max(axis=1) - d[:, :, 0].min(axis=1))
 print('WG total cycles: p50', int(np.percentile(tot, 50)), 'p90', int(np.percentile(tot, 90)), 'p99', int(np.percentile(tot, 99)), 'max', int(tot.max()), 'argmax', int(tot.argmax()), 'of', len(tot))
 print('last 4 WGs (mixed tiles are last):', tot[-4:])
+ends = np.sort(d[:, :, 7].max(axis=1) - t0)
+print('WG end percentiles (cycles from first start): p10 %d p50 %d p90 %d p99 %d max %d' % tuple(int(np.percentile(ends, q)) for q in (10, 50, 90, 99, 100)))
 order = np.argsort(tot)[-6:]
 for i in order:
     print('slow WG', int(i), 'total', int(tot[i]), 'phases w0', [int(d[i, 0, j + 1] - d[i, 0, j]) for j in range(6)])
