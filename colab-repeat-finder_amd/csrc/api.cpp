@@ -406,6 +406,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
 #ifdef PRF_STAMPS
             static u64 *dbg_buf = nullptr;
             if (!dbg_buf) HIPCHK(hipMalloc((void **)&dbg_buf, (size_t)(1 << 20) * 32 * sizeof(u64)));
+            HIPCHK(hipMemsetAsync(dbg_buf, 0, (size_t)(1 << 20) * 32 * sizeof(u64), c->stream));
             a.dbg = dbg_buf;
 #endif
             rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
@@ -446,6 +447,12 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 std::vector<u64> host(nu);
                 HIPCHK(hipMemcpy(host.data(), a.dbg, nu * sizeof(u64), hipMemcpyDeviceToHost));
                 if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, nu, f); fclose(f); }
+                // per-record verify costs of the cooperative pass: [block][idx < 1024]{cycles, info}
+                const size_t nv = (size_t)(a.n_clean + 4 * a.n_mixed) * 1024 * 2;
+                std::vector<u64> hv(nv);
+                HIPCHK(hipMemcpy(hv.data(), a.dbg + (1ull << 24), nv * sizeof(u64), hipMemcpyDeviceToHost));
+                std::string p2 = std::string(path) + ".verify";
+                if (FILE *f = fopen(p2.c_str(), "wb")) { fwrite(hv.data(), 8, nv, f); fclose(f); }
             }
 #endif
             if (getenv("PRF_DEBUG"))

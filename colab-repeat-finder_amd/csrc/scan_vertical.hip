@@ -95,6 +95,9 @@ struct TileCtx {
     u32 min_repeats, min_span;
     u32 lin_off;              // byte offset of the linear window in LDS
     u32 x_in_lds;             // the window holds X too
+#ifdef PRF_STAMPS
+    u64 *dbg;
+#endif
 };
 static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 
@@ -177,8 +180,8 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
 // Candidate records -> rows.  only_list >= 0: the records [0, n) of that wave's list, taken by lanes
 // first, first+stride, ... (a wave emptying its own full list in the middle of the scan).  only_list < 0:
 // the records of all lists, as one index space [0, n) (the cooperative pass at the end of the tile).
-// Returns the number of records this lane handled.  Not inlined: called from two places.
-__device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
+// Not inlined: called from two places.
+__device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     prf_window_view view;
     view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
@@ -200,9 +203,7 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
     const u32 fast_hi = tc.xz_hi > tc.xz_lo ? (u32)LW * 64u - 64u : 0u;  // 0: tile with N in reach, no fast path
     const u32 *rec_cnt = smem_rec_cnt();
     const u32 c0 = rec_cnt[0], c1 = c0 + rec_cnt[1], c2 = c1 + rec_cnt[2];
-    u32 handled = 0;
     for (u32 idx = first; idx < n; idx += stride) {
-        handled++;
         u32 slot_idx;
         if (only_list >= 0) slot_idx = (u32)only_list * REC_PER_WAVE + idx;
         else if (idx < c0) slot_idx = idx;
@@ -210,6 +211,10 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
         else if (idx < c2) slot_idx = 2 * REC_PER_WAVE + (idx - c1);
         else slot_idx = 3 * REC_PER_WAVE + (idx - c2);
         const u64 rec = recs[slot_idx];
+#ifdef PRF_STAMPS
+        const u64 vt0 = __builtin_amdgcn_s_memtime();
+        u32 vslow = 0, vwalk = 0;
+#endif
         const u64 p8 = (rec & ((1ull << 37) - 1ull)) << 3;
         const u32 kind = (u32)(rec >> 37) & 3u;
         const u32 kk = (u32)(rec >> 39) & 511u;
@@ -227,8 +232,14 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
                 a = win_pos0 + fa;
                 b = win_pos0 + fb;
             } else if (st == 2) {
+#ifdef PRF_STAMPS
+                vslow++;
+#endif
                 st = prf_candidate_to_run(view, p, k, kind, min_repeats, min_span, a, b) ? 1 : 0;
             }
+#ifdef PRF_STAMPS
+            if (st == 1) vwalk += (u32)(b - a);
+#endif
             if (st == 1) {
                 const u32 slot = atomicAdd(hit_cnt, 1u);
                 if (slot < hit_cap) {
@@ -241,8 +252,14 @@ __device__ __noinline__ u32 verify_records(prf_lds_cu64 *recs, int only_list, u3
                 }
             }
         }
+#ifdef PRF_STAMPS
+        if (only_list < 0 && tc.dbg) {
+            u64 *d = tc.dbg + (1ull << 24) + ((u64)blockIdx.x * 1024 + idx) * 2;
+            d[0] = __builtin_amdgcn_s_memtime() - vt0;
+            d[1] = (u64)kind | ((u64)kk << 8) | ((u64)vslow << 24) | ((u64)vwalk << 32) | ((rec >> 48 & 255ull) << 56);
+        }
+#endif
     }
-    return handled;
 }
 
 // bit t of the result: bits t .. t+M-1 of z are all ones (M <= 16)
@@ -263,7 +280,7 @@ struct Emit {
     u64 *all_recs;       // all lists
     int wave;
     u32 cnt;             // records in it (wave-uniform)
-    u32 handled;         // records this lane verified in early flushes
+    u32 flushed;         // records verified in early flushes (wave-uniform)
     u64 lane_pos;        // tile base + lane*32
     int lane;
     prf_lds_cu32 *lin_h, *lin_l;  // the linear window in LDS
@@ -299,7 +316,8 @@ struct Emit {
             if (bal == 0) continue;
             const u32 n = (u32)__builtin_popcountll(bal);
             if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
-                handled += verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
+                verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
+                flushed += cnt;
                 cnt = 0;
             }
             if (mask) {
@@ -310,29 +328,35 @@ struct Emit {
         }
     }
 
-    // Every lane of the wave calls this together.  `hot`: bit b set = stream (lane, b) reports for the 8-row
-    // group starting at `row`; c[0..7] are the candidate words whose bit b forms the record's mask.
-    __device__ __forceinline__ void push(u32 hot, const u32 (&c)[8], int row, u64 kind, u32 k) {
-        u64 bal = __builtin_amdgcn_ballot_w64(hot != 0);
-        while (bal) {
-            const u32 n = (u32)__builtin_popcountll(bal);
-            if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
-                handled += verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
-                cnt = 0;
-            }
-            if (hot) {
-                const u32 b = (u32)__builtin_ctz(hot);
+    // Group tasks.  Every lane of the wave calls this together.  `hot`: bit b set = stream (lane, b) reports for the
+    // 8-row group starting at `row`; bit b of c[i] set = it reports for motif size k0+i.  One record per (stream,
+    // motif size): a record that named several sizes would be verified by one lane, size after size, while the
+    // other lanes of its wave wait.
+    __device__ __forceinline__ void push(u32 hot, const u32 (&c)[8], int row, u64 kind, u32 k0) {
+        u32 mask = 0, b = 0;
+        while (__builtin_amdgcn_ballot_w64((hot | mask) != 0) != 0) {
+            if (mask == 0 && hot) {
+                b = (u32)__builtin_ctz(hot);
                 hot &= hot - 1;
-                u32 mask = 0;
                 static_for<0, 8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     mask |= ((c[i] >> b) & 1u) << i;
                 });
+            }
+            const u64 bal = __builtin_amdgcn_ballot_w64(mask != 0);
+            const u32 n = (u32)__builtin_popcountll(bal);
+            if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
+                verify_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane, 64u);
+                flushed += cnt;
+                cnt = 0;
+            }
+            if (mask) {
+                const u32 one = mask & (0u - mask);
+                mask ^= one;
                 const u32 idx = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
-                recs[idx] = make_rec(lane_pos + (u64)b * (64u * T) + (u64)row, kind, k, mask);
+                recs[idx] = make_rec(lane_pos + (u64)b * (64u * T) + (u64)row, kind, k0, one);
             }
             cnt += n;
-            bal = __builtin_amdgcn_ballot_w64(hot != 0);
         }
     }
 };
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
                 lin[idx] = (p == 0 ? g.H : g.L)[w0 + j];
             }
         }
-        if (tid < MAX_WAVES) rec_cnt[tid] = 0;
+        if (tid < 2 * MAX_WAVES + 1 && tid != MAX_WAVES) rec_cnt[tid] = 0;  // list lengths, [MAX_WAVES] = row count, flushed counts
         if (tid == 0) {
             *hit_cnt = 0;
             TileCtx tc;
@@ -663,6 +687,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             tc.min_span = g.min_span;
             tc.lin_off = lin_off;
             tc.x_in_lds = 0u;
+#ifdef PRF_STAMPS
+            tc.dbg = g.dbg;
+#endif
             *reinterpret_cast<TileCtx *>(prf_smem) = tc;
         }
     }
@@ -676,7 +703,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     em.all_recs = recs;
     em.wave = wave;
     em.cnt = 0;
-    em.handled = 0;
+    em.flushed = 0;
     em.lane_pos = tile * PRF_TILE + (u64)lane * T;
     em.lane = lane;
     em.lin_h = (prf_lds_cu32 *)(prf_smem + lin_off);
@@ -689,7 +716,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
 #endif
     if (hasx) run_tasks<true, NC>(vimg, g.plan, wave, lane, tb0, tb1, em, task_dbg);
     else run_tasks<false, NC>(vimg, g.plan, wave, lane, tb0, tb1, em, task_dbg);
-    if (lane == 0) rec_cnt[wave] = em.cnt;  // waves the plan does not use keep the 0 from staging
+    if (lane == 0) {  // waves the plan does not use keep the 0 from staging
+        rec_cnt[wave] = em.cnt;
+        rec_cnt[MAX_WAVES + 1 + wave] = em.flushed;
+    }
     PRF_STAMP(3);
     __syncthreads();
     PRF_STAMP(4);
@@ -697,10 +727,16 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's slab, or nothing ----
     u32 total = 0;
     for (int w = 0; w < MAX_WAVES; w++) total += rec_cnt[w];
-    const u32 n_records = em.handled + verify_records((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);
+    // (statistics: the candidate-record count goes out now, so that the atomic is long acknowledged when the barrier
+    // after the verification waits for outstanding memory operations)
+    if (tid == 0) {
+        u32 n_records = total;
+        for (int w = 0; w < MAX_WAVES; w++) n_records += rec_cnt[MAX_WAVES + 1 + w];
+        if (n_records)
+            atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_records);
+    }
+    verify_records((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);
     PRF_STAMP(5);
-    if (n_records)
-        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_records);
     __syncthreads();
     PRF_STAMP(6);
     // ---- 4. the tile's rows -> the compact row array: ONE atomic per workgroup reserves its range (low 40 bits:
