@@ -221,7 +221,7 @@ def main():
                        "multi_gpu": ("one contig per rank, no data-path collective; one padded RCCL gather of rows to rank 0"
                                      f" (gather verified: {gathered_ok})") if world > 1 else "n/a"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(length, args.kmin, args.kmax),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(length, args.kmin, args.kmax) if (st0.path == 1 and args.workload == "chr22") else None,
                          "kernel": "prf_vscan_kernel (fused scan + verify + row compaction: the only launch of a step)" if st0.path == 1 else "prf_scan_generic_kernel",
                          "kernel_ms": round(p1, 5),
                          "algorithmic_bytes_per_launch": bytes_alg,
