@@ -13,7 +13,9 @@ offline, so the contig is the synthetic stand-in of colab-repeat-finder_amd/synt
 
 N > 1: one process per GPU; every rank scans its own chr22-sized contig (seed 22 + rank; weak scaling, no
 data-path collective) and the rows are then concatenated on rank 0 with one padded RCCL gather, inside
-the timed region (double-buffered: the gather of step i overlaps the scan of step i+1).
+the timed region (a communication thread issues the gathers from a ring of 4 send buffers while the main
+thread scans on: the gather of step i overlaps the scans of the following steps; every gather has completed
+when the timed region ends).
 
 Rank 0 prints ONE JSON line.  `value` is whole-job Gbp/s from the wall clock (max over ranks); the
 `roofline` object prices the dominant kernel with the HIP events recorded around each of its launches in
@@ -126,35 +128,64 @@ def main():
     n_rows_local = len(rows)
     gather_cap = None
     if world > 1:
+        import queue
+        import threading
         cap = torch.tensor([n_rows_local], device=tdev, dtype=torch.int64)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        gather_cap = int(cap.item()) + 1
-        # two send buffers: the gather of step i overlaps the scan of step i+1
-        send_devs = [torch.zeros((gather_cap, 3), dtype=torch.int64, device="cuda") for _ in range(2)]  # 24-byte rows + count row
-        sends = send_devs if tdev == "cuda" else [torch.zeros((gather_cap, 3), dtype=torch.int64) for _ in range(2)]
-        recvs = [[torch.zeros_like(sends[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        pending = [None, None]
-        step_no = [0]
+        gather_cap = int(cap.item()) + 1                                     # 24-byte rows + one count record
+        # The gather of step i runs on a communication thread while the main thread scans step i+1, i+2, ...:
+        # NBUF send buffers cycle between the two (the scan and the collectives release the GIL).
+        NBUF = 4
+        send_devs = [torch.zeros((gather_cap, 3), dtype=torch.int64, device="cuda") for _ in range(NBUF)]
+        sends = send_devs if tdev == "cuda" else [torch.zeros((gather_cap, 3), dtype=torch.int64) for _ in range(NBUF)]
+        recvs = [[torch.zeros_like(sends[0]) for _ in range(world)] if rank == 0 else None for _ in range(NBUF)]
+        free_q, work_q = queue.Queue(), queue.Queue()
+        for b in range(NBUF):
+            free_q.put(b)
+        comm_state = {"last": None, "error": None}
+
+        def comm_loop():
+            try:
+                torch.cuda.set_device(dev_index)
+                comm_stream = torch.cuda.Stream()
+                with torch.cuda.stream(comm_stream):
+                    while True:
+                        b = work_q.get()
+                        if b is None:
+                            return
+                        if sends[b] is not send_devs[b]:
+                            sends[b].copy_(send_devs[b])                     # gloo rehearsal only
+                        dist.gather(sends[b], recvs[b], dst=0)
+                        comm_stream.synchronize()                            # the buffer may be refilled now
+                        comm_state["last"] = b
+                        free_q.put(b)
+            except BaseException as exc:                                     # surfaces in fence()
+                comm_state["error"] = exc
+                free_q.put(-1)
+
+        comm_thread = threading.Thread(target=comm_loop, name="prf-gather", daemon=True)
+        comm_thread.start()
+        in_flight = [0]
+
+    def take_buffer():
+        b = free_q.get()
+        if b < 0:
+            raise RuntimeError("gather thread failed") from comm_state["error"]
+        return b
 
     def step():
         _, st = scan(False)
         if world > 1:
-            b = step_no[0] & 1
-            step_no[0] += 1
-            if pending[b] is not None:
-                pending[b].wait()                                                # the gather that used this buffer 2 steps ago
-            n = ctx.last_hits_to_device(send_devs[b].data_ptr(), gather_cap - 1)  # device-to-device, rows stay in HBM
-            send_devs[b][gather_cap - 1, 0] = n
-            if sends[b] is not send_devs[b]:
-                sends[b].copy_(send_devs[b])                                     # gloo rehearsal only
-            pending[b] = dist.gather(sends[b], recvs[b], dst=0, async_op=True)
+            b = take_buffer()                                                # blocks only if all NBUF gathers are pending
+            ctx.last_hits_to_device(send_devs[b].data_ptr(), gather_cap - 1, count_row=True)  # device-to-device
+            work_q.put(b)
         return st
 
     def fence():
         if world > 1:
-            for w in pending:
-                if w is not None:
-                    w.wait()
+            held = [take_buffer() for _ in range(NBUF)]                      # every gather issued so far has completed
+            for b in held:
+                free_q.put(b)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +220,7 @@ def main():
     gathered_ok = None
     if world > 1 and rank == 0:
         # the last gather must hold every rank's rows: counts add up and rank 0's part equals its own fetched rows
-        recv = recvs[(step_no[0] - 1) & 1]
+        recv = recvs[comm_state["last"]]
         counts = [int(r[gather_cap - 1, 0].item()) for r in recv]
         mine = recv[0][:counts[0]].cpu().numpy().view(np.uint8).reshape(-1, 24)
         ref = np.ascontiguousarray(rows).view(np.uint8).reshape(-1, 24)
@@ -240,6 +271,8 @@ def main():
     genome.free()
     ctx.close()
     if world > 1:
+        work_q.put(None)
+        comm_thread.join()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -543,15 +543,18 @@ int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin
     return rc;
 }
 
-int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, uint64_t *n_rows) {
-    if (!c || !n_rows || (capacity_rows && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
+int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, int count_row, uint64_t *n_rows) {
+    if (!c || !n_rows || ((capacity_rows || count_row) && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
     HIPCHK(hipSetDevice(c->dev));
     *n_rows = c->last_nhits;
     const u64 n = std::min<u64>(c->last_nhits, capacity_rows);
-    if (n) {
-        HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
+    if (count_row) {  // staged in the spare words behind the counter block (pinned); the stream is drained below
+        u64 *stage = c->h_counters + PRF_CNT_N + 2;
+        stage[0] = n; stage[1] = 0; stage[2] = 0;
+        HIPCHK(hipMemcpyAsync((prf_hit_dev *)dst + capacity_rows, stage, sizeof(prf_hit_dev), hipMemcpyHostToDevice, c->stream));
     }
+    if (n || count_row) HIPCHK(hipStreamSynchronize(c->stream));
     return PRF_OK;
 }
 

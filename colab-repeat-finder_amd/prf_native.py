@@ -96,7 +96,7 @@ def load_library():
         lib.prf_free_hits.argtypes = [ctypes.POINTER(_Hits)]
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-        lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -222,10 +222,12 @@ class Context:
         finally:
             self.lib.prf_free_hits(ctypes.byref(hits))
 
-    def last_hits_to_device(self, dst_ptr, capacity_rows):
-        """D2D copy of the last scan's rows into caller-owned device memory; returns the row count."""
+    def last_hits_to_device(self, dst_ptr, capacity_rows, count_row=False):
+        """D2D copy of the last scan's rows into caller-owned device memory; returns the row count.
+        count_row: record number capacity_rows of the buffer receives (rows copied, 0, 0)."""
         n = ctypes.c_uint64(0)
-        _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows, ctypes.byref(n)))
+        _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows,
+                                                          1 if count_row else 0, ctypes.byref(n)))
         return n.value
 
     def scan_timings(self, first_seq, n):

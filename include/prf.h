@@ -131,8 +131,11 @@ void prf_free_hits(prf_hits *hits);
 
 /* Device-side hand-off of the rows of the LAST prf_scan_genome() on this context (unsorted, 24-byte
  * prf_hit records): copied device-to-device into caller-owned device memory (e.g. a torch tensor that
- * an RCCL gather then ships to rank 0).  *n_rows receives the row count; at most capacity_rows are copied. */
-int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, uint64_t *n_rows);
+ * an RCCL gather then ships to rank 0).  *n_rows receives the row count; at most capacity_rows are copied.
+ * count_row != 0: the record at index capacity_rows (the buffer must hold capacity_rows+1 records) receives
+ * {start = number of rows copied, end = 0, k = 0, contig = 0}, so that a padded gather carries its own length.
+ * The copy is complete when the call returns. */
+int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, int count_row, uint64_t *n_rows);
 
 /* ---- the data formats either side of the path (host code, no GPU) ------------------------------------------
  * FASTA reader: what the reference takes from pyfastx.Fasta (perfect_repeat_finder.py:117,130,136-143): entries in
