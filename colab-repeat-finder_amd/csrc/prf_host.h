@@ -5,7 +5,7 @@
 #include "prf_device.h"
 
 // device counter block (u64 each)
-#define PRF_ROWS_TICKET_SHIFT 40
+#define PRF_ROWS_TICKET_SHIFT 40  // PRF_CNT_ROWS: row cursor below this bit, finished workgroups from it up
 
 enum {
     PRF_CNT_CAND = 0,     // generic path: phase-1 candidates
@@ -14,10 +14,9 @@ enum {
     PRF_CNT_HIT_OVF = 4,  // fused path: largest per-tile row demand above the slab capacity
     PRF_CNT_ROWS = 5,     // fused path: [39:0] cursor of the compact row array, [63:40] workgroups finished (one
                           // atomic per workgroup does both; the last workgroup hands the counters to the host)
-    PRF_CNT_SHARD0 = 8,   // fused path: per-shard sums, one 64-byte line per shard
+    PRF_CNT_SHARD0 = 8,   // fused path: candidate-record counts (statistics), sharded over 16 cache lines by tile
     PRF_CNT_NSHARD = 16,
     PRF_CNT_SHARD_STRIDE = 8,
-    PRF_SH_HITS = 0,
     PRF_SH_CAND = 1,
     PRF_CNT_N = 8 + 16 * 8
 };

@@ -16,6 +16,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
+    # torch first: one test hands rows to a torch tensor, and torch's bundled HIP runtime must be the one the
+    # process loads (bench.py imports in the same order); libprf alone runs on the system runtime.
+    import torch
+    assert torch.cuda.is_available()
     import prf_native
     c = prf_native.Context(0)
     yield c
@@ -241,6 +245,39 @@ def test_config_c5_share_random_1250mbp_motif_1_100(ctx):
             sel = (starts >= off + margin) & (ends <= off + win - margin)
             got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
             assert got == want and len(want) > 300, off
+    finally:
+        g.free()
+
+
+def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
+    """PRF_SCAN_DEFER_TIMING + prf_scan_timings (what bench.py's timed loop uses) and the device-to-device
+    hand-off of rows with the trailing count record (what its multi-GPU gather ships)."""
+    import prf_native
+    import synth
+    import torch
+    seq = synth.chr_standin(length=400_000, seed=9, n_head=30_000, n_tail=2_000, repeats_per_mbp=3000).tobytes()
+    g = ctx.load([seq], 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.n_launches == 1 and st.phase1_ms > 0 and st.seq > 0
+        seqs = []
+        for _ in range(5):
+            none, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_DEFER_TIMING, fetch=False)
+            assert none is None and st2.phase1_ms == 0 and st2.n_hits == len(rows)
+            seqs.append(st2.seq)
+        assert seqs == list(range(seqs[0], seqs[0] + 5))
+        ms = ctx.scan_timings(seqs[0], 5)
+        assert len(ms) == 5 and all(0 < m < 50 for m in ms)
+        with pytest.raises(prf_native.PrfError):
+            ctx.scan_timings(seqs[-1] + 1, 1)               # not issued yet
+        cap = len(rows) + 7
+        buf = torch.full((cap + 1, 3), -1, dtype=torch.int64, device="cuda")
+        n = ctx.last_hits_to_device(buf.data_ptr(), cap, count_row=True)
+        host = buf.cpu().numpy()
+        assert n == len(rows) and host[cap].tolist() == [n, 0, 0] and (host[n:cap] == -1).all()
+        got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
+        got = got[np.lexsort((got["end"], got["start"], got["contig"]))]
+        assert np.array_equal(got, rows)
     finally:
         g.free()
 
