@@ -79,7 +79,7 @@ __device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
     return (pos >> 3) | (kind << 37) | ((u64)k << 39) | ((u64)mask << 48);
 }
 
-// dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
+// dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64][cof: COF_WORDS u32]
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
 constexpr int SMEM_HDR = 192;
 
@@ -103,6 +103,26 @@ static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 
 __device__ __forceinline__ u32 *smem_rec_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128); }
 __device__ __forceinline__ u32 *smem_hit_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128 + 4 * MAX_WAVES); }
+
+// cof[k]: the cofactors k/p of the distinct primes p | k, one per byte, largest first (k <= 480 has at most 4
+// distinct primes and k/p <= 240).  The motif seq[a:a+k] is primitive iff it has none of these periods
+// (reference consists_of_perfect_repeats, utils/perfect_repeat_tracker.py:108-142, tries every divisor).
+struct CofTable {
+    u32 v[PRF_VMAX_K + 1];
+    constexpr CofTable() : v{} {
+        for (u32 k = 2; k <= PRF_VMAX_K; k++) {
+            u32 rest = k, packed = 0, n = 0;
+            for (u32 p = 2; p <= rest; p++) {
+                if (rest % p) continue;
+                packed |= (k / p) << (8 * n++);
+                while (rest % p == 0) rest /= p;
+            }
+            v[k] = packed;
+        }
+    }
+};
+__constant__ const CofTable prf_cof_table{};
+constexpr int COF_WORDS = (PRF_VMAX_K + 1 + 3) & ~3;  // LDS copy behind the candidate lists
 
 // ---- lean verification for the common case: a candidate well inside a clean tile ----
 // All looks are 32 positions wide and read the LDS window only (H and L; the not-ACGT plane is known to be
@@ -129,7 +149,7 @@ __device__ __forceinline__ bool has_period32(prf_lds_cu32 *h, prf_lds_cu32 *l, u
     return true;
 }
 // 0: not a row; 1: row, run [a, b) in window positions; 2: outside the fast path's reach -> generic routine
-__device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 p, u32 k, u32 kind, u32 min_repeats,
+__device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, prf_lds_cu32 *cof, u32 p, u32 k, u32 kind, u32 min_repeats,
                                               u32 min_span, u32 lo_ok, u32 hi_ok, u32 &a_out, u32 &b_out) {
     if (p < lo_ok + 32u || p + k + 64u > hi_ok) return 2;
     const u32 back = kind == (u32)PRF_KIND_START ? 1u : (8u << (kind - 1u));  // 1, 8, 16, 32
@@ -148,30 +168,9 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
         b += 32u;
     }
     if ((long long)(b - a) < prf_min_matches(k, min_repeats, min_span)) return 0;
-    // primitive motif: no period k/q for a prime q | k
-    u32 rest = k;
-#define PRF_TRY_PRIME32(P)                                   \
-    if (rest % P == 0) {                                     \
-        if (has_period32(h, l, a, k, k / P)) return 0; \
-        do rest /= P; while (rest % P == 0);                 \
-    }
-    if (k >= 2) {
-        PRF_TRY_PRIME32(2u)
-        PRF_TRY_PRIME32(3u)
-        if (rest > 1) {
-            PRF_TRY_PRIME32(5u)
-            PRF_TRY_PRIME32(7u)
-            if (rest > 1) {
-                PRF_TRY_PRIME32(11u)
-                PRF_TRY_PRIME32(13u)
-                PRF_TRY_PRIME32(17u)
-                PRF_TRY_PRIME32(19u)
-                PRF_TRY_PRIME32(23u)
-                if (rest > 1 && has_period32(h, l, a, k, k / rest)) return 0;  // k <= 480 < 29*29: rest is prime
-            }
-        }
-    }
-#undef PRF_TRY_PRIME32
+    // primitive motif: no period k/p for a prime p | k
+    for (u32 cf = cof[k]; cf; cf >>= 8)
+        if (has_period32(h, l, a, k, cf & 255u)) return 0;
     a_out = a;
     b_out = b;
     return 1;
@@ -199,6 +198,7 @@ __device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u
     const u64 win_pos0 = tc.w0 * 64;
     prf_lds_cu32 *fh = (prf_lds_cu32 *)(prf_smem + tc.lin_off);
     prf_lds_cu32 *fl = fh + 2 * LW;
+    prf_lds_cu32 *cof = fl + 2 * LW + 2 * MAX_WAVES * REC_PER_WAVE;  // behind the candidate lists
     const u32 fast_lo = 64u;                                             // the tile starts 64 positions into the window
     const u32 fast_hi = tc.xz_hi > tc.xz_lo ? (u32)LW * 64u - 64u : 0u;  // 0: tile with N in reach, no fast path
     const u32 *rec_cnt = smem_rec_cnt();
@@ -227,7 +227,7 @@ __device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u
             u64 a, b;
             u32 fa, fb;
             int st = 2;
-            if (fast_hi) st = fast_candidate(fh, fl, (u32)(p - win_pos0), k, kind, min_repeats, min_span, fast_lo, fast_hi, fa, fb);
+            if (fast_hi) st = fast_candidate(fh, fl, cof, (u32)(p - win_pos0), k, kind, min_repeats, min_span, fast_lo, fast_hi, fa, fb);
             if (st == 1) {
                 a = win_pos0 + fa;
                 b = win_pos0 + fb;
@@ -670,6 +670,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
                 lin[idx] = (p == 0 ? g.H : g.L)[w0 + j];
             }
         }
+        {
+            u32 *cof_lds = reinterpret_cast<u32 *>(recs + MAX_WAVES * REC_PER_WAVE);
+            for (int i = tid; i <= (int)PRF_VMAX_K; i += nt) cof_lds[i] = prf_cof_table.v[i];
+        }
         if (tid < 2 * MAX_WAVES + 1 && tid != MAX_WAVES) rec_cnt[tid] = 0;  // list lengths, [MAX_WAVES] = row count, flushed counts
         if (tid == 0) {
             *hit_cnt = 0;
@@ -909,7 +913,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     const u32 need_nc = 64 + (24 + reach) / T;  // the last block starts at row 24; virtual lanes 64 .. 63+offset
     plan->nc = need_nc <= 66 ? 66 : (need_nc <= 72 ? 72 : 80);  // the widths the kernel is instantiated for
     plan->lds_bytes = (u32)(SMEM_HDR + (size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
-                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64));
+                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (size_t)COF_WORDS * sizeof(u32));
     return true;
 }
 
