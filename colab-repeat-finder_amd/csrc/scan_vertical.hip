@@ -152,11 +152,15 @@ __device__ __forceinline__ bool has_period32(prf_lds_cu32 *h, prf_lds_cu32 *l, u
 __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, prf_lds_cu32 *cof, u32 p, u32 k, u32 kind, u32 min_repeats,
                                               u32 min_span, u32 lo_ok, u32 hi_ok, u32 &a_out, u32 &b_out) {
     if (p < lo_ok + 32u || p + k + 64u > hi_ok) return 2;
-    const u32 back = kind == (u32)PRF_KIND_START ? 1u : (8u << (kind - 1u));  // 1, 8, 16, 32
-    const u32 before = mismatch32(h, l, p - 32u, k);  // bit 31 = position p-1
-    const u32 nmatch = (u32)__builtin_clz(before | 1u);   // matches directly before p (31 if none seen: >= back then)
-    if (before == 0 || nmatch >= back) return 0; // START: p sits inside a run; GROUP*: an earlier examined group reports
-    const u32 a = p - nmatch;
+    u32 a = p;  // START (exact tasks): p is the first position of its run -- the tasks know the row before every
+                // stream but a tile's first, and candidates there take the generic routine (p < lo_ok + 32)
+    if (kind != (u32)PRF_KIND_START) {
+        const u32 back = 8u << (kind - 1u);                   // 8, 16, 32
+        const u32 before = mismatch32(h, l, p - 32u, k);      // bit 31 = position p-1
+        const u32 nmatch = (u32)__builtin_clz(before | 1u);   // matches directly before p (31 if none seen: >= back then)
+        if (before == 0 || nmatch >= back) return 0;          // an earlier examined group of the run reports
+        a = p - nmatch;
+    }
     u32 b = p;
     for (;;) {
         if (b + k + 64u > hi_ok) return 2;
@@ -169,8 +173,12 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
     }
     if ((long long)(b - a) < prf_min_matches(k, min_repeats, min_span)) return 0;
     // primitive motif: no period k/p for a prime p | k
-    for (u32 cf = cof[k]; cf; cf >>= 8)
-        if (has_period32(h, l, a, k, cf & 255u)) return 0;
+    // (START: the periods 1 and 2 were decided when the record was pushed, see Emit::push_start)
+    const u32 dmin = kind == (u32)PRF_KIND_START ? 3u : 1u;
+    for (u32 cf = cof[k]; cf; cf >>= 8) {
+        const u32 d = cf & 255u;
+        if (d >= dmin && has_period32(h, l, a, k, d)) return 0;
+    }
     a_out = a;
     b_out = b;
     return 1;
@@ -470,7 +478,28 @@ __device__ __forceinline__ void exact_task(const uint4 *vimg, int lane, u32 k, i
     constexpr int NGB = (NR + 3) / 4;      // 16-byte slots of base rows
     constexpr int NGS = (O + NR + 3) / 4;  // 16-byte slots of the rows shifted by k (first one starts O rows early)
     const uint4 *lane_base = vimg + lane;
-    u32 mprev = ~0u;  // mismatch word of the row before the block; unknown at the first block -> report, verify decides
+    u32 mprev = ~0u;  // mismatch word of the row before the block; unknown -> report, verify decides
+    if (tb0 == 0) {
+        // Row -1 of stream (lane, b) is row T-1 of stream (lane-1, b); for lane 0 it is row T-1 of stream (63, b-1):
+        // lane 63's word one bit up, with bit 0 (the previous tile's last stream) unknown.  Its partner, row k-1 of
+        // the own stream, lies in the first slots (k <= 14).  With this, a reported start IS the start of its run
+        // everywhere but at the first position of a tile.
+        const int pl = (lane + 63) & 63;
+        const uint4 *pp = vimg + pl + (RG - 1) * NC;
+        const uint4 *ps = lane_base + (int)((k - 1) >> 2) * NC;
+        u32 v = 0;
+        static_for<0, NP>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            u32 prev_row = pp[p * PS].w;
+            if (lane == 0) prev_row <<= 1;
+            const uint4 sv = ps[p * PS];
+            constexpr int c = (O + 3) & 3;  // (k - 1) % 4
+            const u32 own_row = c == 0 ? sv.x : (c == 1 ? sv.y : (c == 2 ? sv.z : sv.w));
+            if constexpr (p < 2) v |= prev_row ^ own_row;
+            else v |= prev_row | own_row;
+        });
+        mprev = lane == 0 ? (v | 1u) : v;
+    }
 #pragma unroll 1
     for (int tb = tb0; tb < tb1; tb++) {
         u32 a[3][4 * NGB];
