@@ -34,6 +34,10 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+             133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+             58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569]   # chr1-22, X, Y, M
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
@@ -80,9 +84,11 @@ def main():
     ap.add_argument("--cpu-sample-bp", type=int, default=12_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel")
-    ap.add_argument("--workload", choices=["chr22", "random"], default="chr22",
+    ap.add_argument("--workload", choices=["chr22", "random", "hg38"], default="chr22",
                     help="chr22: the default stand-in contig (BASELINE config C2, the headline); random: uniform ACGT "
-                         "generated on the device (config C5 is --workload random --length 1250000000 --kmax 100)")
+                         "generated on the device (config C5 is --workload random --length 1250000000 --kmax 100); "
+                         "hg38: 25 contigs with the hg38 primary-assembly lengths (3.09 Gbp of random ACGT generated "
+                         "on the device), dealt to the ranks longest first (config C4's shape; strong scaling)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +119,15 @@ def main():
     length = args.length or synth.CHR22_LEN
     n_head = 10_510_000 if length >= 20_000_000 else length // 10
     ctx = prf_native.Context(dev_index)
-    if args.workload == "random":
+    total_bp = length * world
+    if args.workload == "hg38":
+        import multi_gpu
+        mine = multi_gpu.plan_contig_shards(HG38_LENS, world)[rank]          # what scan_contigs_sharded() does
+        genome = ctx.synth([HG38_LENS[i] for i in mine], [1000 + i for i in mine], args.kmax)
+        seq = None
+        length = sum(HG38_LENS[i] for i in mine)                             # this rank's positions
+        total_bp = sum(HG38_LENS)
+    elif args.workload == "random":
         genome = ctx.synth([length], [22 + rank], args.kmax)        # generated in HBM, nothing crosses PCIe
         seq = None
     else:
@@ -228,7 +242,6 @@ def main():
         gathered_ok = bool(sum(counts) == n_rows_total and counts[0] == n_rows_local and np.array_equal(order(mine), order(ref)))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        total_bp = length * world
         value = total_bp / (elapsed / args.steps) / 1e9
         p1 = float(np.mean(p1_ms))
         # algorithmic bytes per launch of the dominant kernel: the 2-bit input once for all k,
@@ -239,11 +252,14 @@ def main():
         out = {
             "metric": f"Gbp/s scanned (motif {args.kmin}-{args.kmax})", "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 bitplanes (2-bit bases)",
+            "higher_is_better": True, "scaling": "strong" if args.workload == "hg38" else "weak", "vs_baseline": None, "dtype": "u64 bitplanes (2-bit bases)",
             "data": "synthetic",
             "config": {"workload": (f"chr22-sized synthetic stand-in contig per GPU ({length} bp; hg38-like N blocks, "
                                     "planted repeats)" if args.workload == "chr22" else
-                                    f"uniform random ACGT contig per GPU ({length} bp, generated on the device)") +
+                                    f"uniform random ACGT contig per GPU ({length} bp, generated on the device)"
+                                    if args.workload == "random" else
+                                    f"25 contigs with the hg38 primary-assembly lengths ({total_bp} bp of random ACGT "
+                                    f"generated on the device) dealt to {world} rank(s) longest first, rank 0 holds {length} bp") +
                                    f", motif {args.kmin}-{args.kmax}, min_repeats {args.min_repeats}, "
                                    f"min_span {args.min_span}; genome packed + resident in HBM before the timed region",
                        "kernel_path": "generic" if st0.path == 0 else "vertical",
@@ -264,7 +280,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N=1 only
             if seq is None:
                 from oracle import prf_oracle
-                seq = prf_oracle.synth(min(length, args.cpu_sample_bp), 22 + rank)
+                seq = prf_oracle.synth(min(HG38_LENS[0] if args.workload == 'hg38' else length, args.cpu_sample_bp),
+                                       1000 if args.workload == 'hg38' else 22 + rank)
             out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,
                                                args.cpu_sample_bp)
         print(json.dumps(out), flush=True)

@@ -249,6 +249,52 @@ def test_config_c5_share_random_1250mbp_motif_1_100(ctx):
         g.free()
 
 
+HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+             133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+             58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569, 0, 4262]
+
+
+def test_config_c4_hg38_sized_genome_on_one_gpu(ctx):
+    """BASELINE config C4's input shape on ONE GPU: 27 contigs with the hg38 primary-assembly lengths (plus chrM, an
+    empty and a tiny one), 3.09 Gbp of device-generated random ACGT, motif 1-50, one resident genome, one launch.
+    Checks: row-set properties per contig, fused == generic row for row, and the oracle on a window at the START
+    and at the END of several contigs (contig edges are where the guard gaps and the end-of-contig rule act)."""
+    import prf_native
+    from oracle import prf_oracle
+    seeds = [1000 + i for i in range(len(HG38_LENS))]
+    g = ctx.synth(HG38_LENS, seeds, 50)
+    try:
+        rows, stats = g.scan(1, 50, 3, 9)
+        assert stats.path == 1 and stats.positions == sum(HG38_LENS) and stats.n_launches == 1
+        contig = rows["contig"].astype(np.int64)
+        starts = rows["start"].astype(np.int64)
+        ends = rows["end"].astype(np.int64)
+        ks = rows["k"].astype(np.int64)
+        assert len(rows) > 500_000
+        order_ok = (contig[1:] > contig[:-1]) | ((contig[1:] == contig[:-1]) & (
+            (starts[1:] > starts[:-1]) | ((starts[1:] == starts[:-1]) & (ends[1:] > ends[:-1]))))
+        assert order_ok.all()
+        assert np.all(ends <= np.array(HG38_LENS, dtype=np.int64)[contig]) and np.all(ends - starts >= np.maximum(3 * ks, 9))
+        rows2, stats2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert stats2.path == 0 and np.array_equal(rows, rows2)
+        win = 1_500_000
+        for c in (0, 7, 21, 23, 24, 26):
+            n = HG38_LENS[c]
+            for off in sorted({0, max(0, n - win)}):
+                m = min(win, n - off)
+                chunk = prf_oracle.synth(m, seeds[c], start=off)
+                # rows that touch the window's inner edge are cut by the window, not by the contig: leave them out
+                lo = off + (1_000 if off > 0 else 0)
+                hi = off + m - (1_000 if off + m < n else 0)
+                want = [(s + off, e + off, k) for s, e, _m, k in prf_oracle.detect_rows(chunk, 1, 50, 3, 9)
+                        if s + off >= lo and e + off <= hi]
+                sel = (contig == c) & (starts >= lo) & (ends <= hi)
+                got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
+                assert got == want, (c, off)
+    finally:
+        g.free()
+
+
 def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
     """PRF_SCAN_DEFER_TIMING + prf_scan_timings (what bench.py's timed loop uses) and the device-to-device
     hand-off of rows with the trailing count record (what its multi-GPU gather ships)."""
