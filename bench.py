@@ -188,11 +188,13 @@ def main():
         return b
 
     def step():
-        _, st = scan(False)
         if world > 1:
             b = take_buffer()                                                # blocks only if all NBUF gathers are pending
-            ctx.last_hits_to_device(send_devs[b].data_ptr(), gather_cap - 1, count_row=True)  # device-to-device
+            ctx.set_row_sink(send_devs[b].data_ptr(), gather_cap - 1)       # the kernel compacts the rows straight into the
+            _, st = scan(False)                                             # send buffer and writes the count record
             work_q.put(b)
+        else:
+            _, st = scan(False)
         return st
 
     def fence():
@@ -285,6 +287,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,
                                                args.cpu_sample_bp)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        ctx.set_row_sink(None, 0)
     genome.free()
     ctx.close()
     if world > 1:

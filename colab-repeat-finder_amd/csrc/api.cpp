@@ -72,6 +72,9 @@ struct prf_ctx {
     u64 cand_cap = 0;
     prf_hit_dev *d_hits = nullptr;  // flat rows: generic path output, or the compacted rows of the fused path
     u64 hit_cap = 0;
+    prf_hit_dev *sink = nullptr;    // caller-owned device array the rows go to instead (prf_set_row_sink)
+    u64 sink_cap = 0;
+    const prf_hit_dev *last_rows = nullptr;  // where the rows of the last scan are
     // fused (bit-sliced) path scratch: one row slab per tile
     prf_hit_dev *d_hit_slabs = nullptr;
     u64 slab_tiles = 0;
@@ -395,6 +398,10 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             if (a.n_clean + a.n_mixed == 0) {  // nothing but N (or no contig at all): no tile to launch, no rows
                 nhits = ncand = 0;
                 launches = 0;
+                if (c->sink) {
+                    HIPCHK(hipMemsetAsync(c->sink + c->sink_cap, 0, sizeof(prf_hit_dev), c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                }
                 break;
             }
             a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
@@ -411,7 +418,9 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
 #endif
             rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
             if (rc) return rc;
-            a.rows = c->d_hits; a.rows_cap = c->hit_cap;
+            a.rows = c->sink ? c->sink : c->d_hits;
+            a.rows_cap = c->sink ? c->sink_cap : c->hit_cap;
+            a.count_row = c->sink ? 1u : 0u;
             // ONE kernel per scan: it also compacts the rows (a reservation per workgroup in the row array), hands
             // the counters to the host through mapped memory and clears the counter block of the next scan
             hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
@@ -424,6 +433,8 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             // Everything that consumes the rows is enqueued on the same stream, hence ordered after the kernel.
             rc = wait_for_seq(c, a.seq);
             if (rc) return rc;
+            // a row sink is read by the caller on streams of its own: wait until every workgroup has copied its rows
+            if (c->sink) HIPCHK(hipStreamSynchronize(c->stream));
             if (stats && !(flags & PRF_SCAN_DEFER_TIMING)) {
                 HIPCHK(hipEventSynchronize(ev_b));
                 HIPCHK(hipEventElapsedTime(&ms01, ev_a, ev_b));
@@ -460,7 +471,10 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                         (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
-            if (!again && nhits > c->hit_cap) {  // the compact row array was too small: grow it and scan again
+            if (!again && c->sink && nhits > c->sink_cap)
+                return fail(PRF_EINVAL, "the row sink holds %llu rows, the scan found %llu", (unsigned long long)c->sink_cap,
+                            (unsigned long long)nhits);
+            if (!again && !c->sink && nhits > c->hit_cap) {  // the compact row array was too small: grow it and scan again
                 want_hits = nhits + nhits / 8 + 1024;
                 again = true;
             }
@@ -485,10 +499,21 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             nhits = c->h_counters[PRF_CNT_HITS];
             if (ncand > c->cand_cap) { want_cand = ncand + ncand / 8 + 1024; again = true; }
             if (nhits > c->hit_cap) { want_hits = nhits + nhits / 8 + 1024; again = true; }
+            if (!again && c->sink) {  // the generic kernels write the internal array: hand the rows over afterwards
+                if (nhits > c->sink_cap)
+                    return fail(PRF_EINVAL, "the row sink holds %llu rows, the scan found %llu", (unsigned long long)c->sink_cap,
+                                (unsigned long long)nhits);
+                u64 *stage = c->h_counters + PRF_CNT_N + 2;
+                stage[0] = nhits; stage[1] = 0; stage[2] = 0;
+                if (nhits) HIPCHK(hipMemcpyAsync(c->sink, c->d_hits, nhits * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(c->sink + c->sink_cap, stage, sizeof(prf_hit_dev), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
         }
         if (!again) break;
     }
     c->last_nhits = nhits;
+    c->last_rows = c->sink ? c->sink : c->d_hits;
     if (stats) {
         stats->phase1_ms = ms01;
         stats->phase2_ms = ms12;
@@ -506,7 +531,10 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     prf_hit *rows = (prf_hit *)malloc(nhits * sizeof(prf_hit));
     if (!rows) return fail(PRF_ENOMEM, "prf_scan_genome: cannot allocate %llu rows", (unsigned long long)nhits);
     static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
-    hipError_t e = hipMemcpy(rows, c->d_hits, nhits * sizeof(prf_hit), hipMemcpyDeviceToHost);
+    // on the library's stream: the scan returned when the counters were posted, the last workgroups may still be
+    // copying their rows, and the stream is a non-blocking one (the null stream does not wait for it)
+    hipError_t e = hipMemcpyAsync(rows, c->last_rows, nhits * sizeof(prf_hit), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         free(rows);
         return fail(PRF_EHIP, "row copy failed: %s", hipGetErrorString(e));
@@ -543,12 +571,20 @@ int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin
     return rc;
 }
 
+int prf_set_row_sink(prf_ctx *c, void *dst_device, uint64_t capacity_rows) {
+    if (!c) return fail(PRF_EINVAL, "prf_set_row_sink: NULL context");
+    c->sink = (prf_hit_dev *)dst_device;
+    c->sink_cap = dst_device ? capacity_rows : 0;
+    return PRF_OK;
+}
+
 int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, int count_row, uint64_t *n_rows) {
     if (!c || !n_rows || ((capacity_rows || count_row) && !dst)) return fail(PRF_EINVAL, "prf_last_hits_to_device: bad arguments");
     HIPCHK(hipSetDevice(c->dev));
     *n_rows = c->last_nhits;
     const u64 n = std::min<u64>(c->last_nhits, capacity_rows);
-    if (n) HIPCHK(hipMemcpyAsync(dst, c->d_hits, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
+    if (n && dst != (void *)c->last_rows)
+        HIPCHK(hipMemcpyAsync(dst, c->last_rows, n * sizeof(prf_hit_dev), hipMemcpyDeviceToDevice, c->stream));
     if (count_row) {  // staged in the spare words behind the counter block (pinned); the stream is drained below
         u64 *stage = c->h_counters + PRF_CNT_N + 2;
         stage[0] = n; stage[1] = 0; stage[2] = 0;

@@ -49,6 +49,7 @@ struct prf_vscan_args {
     u32 hit_cap;
     prf_hit_dev *rows;             // the compact row array: every workgroup reserves its range with one atomic
     u64 rows_cap;
+    u32 count_row;                 // the last workgroup also writes {rows, 0, 0} as record rows[rows_cap]
     u32 min_repeats, min_span;
     const u64 *contig_base;
     u32 n_contigs;

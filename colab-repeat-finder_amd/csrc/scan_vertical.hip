@@ -805,8 +805,17 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     PRF_STAMP(7);
     if (ticket == (u64)gridDim.x - 1ull) {
         for (u32 i = (u32)tid; i < (u32)PRF_CNT_N; i += (u32)nt) {
-            g.host_counters[i] = atomicAdd(&g.counters[i], 0ull);
+            const u64 v = atomicAdd(&g.counters[i], 0ull);
+            g.host_counters[i] = v;
             g.next_counters[i] = 0;
+            if (i == (u32)PRF_CNT_ROWS && g.count_row) {  // a caller-owned row array carries its own length
+                prf_hit_dev h;
+                h.start = v & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+                h.end = 0;
+                h.k = 0;
+                h.contig = 0;
+                g.rows[g.rows_cap] = h;
+            }
         }
         __threadfence_system();
         __syncthreads();

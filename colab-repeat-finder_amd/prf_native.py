@@ -58,7 +58,7 @@ class ScanStats(ctypes.Structure):
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
-           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings"]
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -97,6 +97,7 @@ def load_library():
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_set_row_sink.argtypes = [vp, vp, ctypes.c_uint64]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -229,6 +230,11 @@ class Context:
         _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows,
                                                           1 if count_row else 0, ctypes.byref(n)))
         return n.value
+
+    def set_row_sink(self, dst_ptr, capacity_rows):
+        """Following scans compact their rows into caller-owned device memory (capacity_rows + 1 records, the last
+        one receives the row count); dst_ptr None/0 switches back to the library's own array."""
+        _check(self.lib, self.lib.prf_set_row_sink(self._h, ctypes.c_void_p(dst_ptr or None), capacity_rows))
 
     def scan_timings(self, first_seq, n):
         """HIP-event kernel times (ms) of n fused scans from serial number first_seq (ScanStats.seq) on."""

@@ -123,6 +123,13 @@ int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t k
 int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax,
              uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
 
+/* Row sink: the rows of the following scans on this context are compacted straight into caller-owned device
+ * memory (e.g. the send buffer of an RCCL gather) instead of the library's own array.  dst_device must hold
+ * capacity_rows + 1 prf_hit records; record number capacity_rows receives {start = number of rows, 0, 0, 0}.
+ * With a sink set, prf_scan_genome returns only when all rows are in place (it drains its stream), and fails with
+ * PRF_EINVAL if the scan finds more than capacity_rows rows.  dst_device == NULL: back to the internal array. */
+int prf_set_row_sink(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows);
+
 /* HIP-event kernel times (ms) of the fused scans first_seq .. first_seq+n-1 of this context (prf_scan_stats.seq);
  * they must be among its last PRF_TIMING_RING fused scans.  Waits for those scans' events. */
 int prf_scan_timings(prf_ctx *ctx, uint64_t first_seq, uint32_t n, float *kernel_ms);

@@ -324,7 +324,26 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
         got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
         got = got[np.lexsort((got["end"], got["start"], got["contig"]))]
         assert np.array_equal(got, rows)
+        # row sink: the kernel compacts the rows straight into caller-owned memory, count record behind them;
+        # both kernel paths, a fetch through the sink, and a sink that is too small
+        for fl in (prf_native.SCAN_DEFAULT, prf_native.SCAN_FORCE_GENERIC):
+            buf.fill_(-1)
+            torch.cuda.synchronize()
+            ctx.set_row_sink(buf.data_ptr(), cap)
+            rows3, st3 = g.scan(1, 50, 3, 9, flags=fl)
+            assert np.array_equal(rows3, rows)
+            host = buf.cpu().numpy()
+            assert host[cap].tolist() == [n, 0, 0] and (host[n:cap] == -1).all()
+            got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
+            assert np.array_equal(got[np.lexsort((got["end"], got["start"], got["contig"]))], rows)
+        ctx.set_row_sink(buf.data_ptr(), 10)
+        with pytest.raises(prf_native.PrfError):
+            g.scan(1, 50, 3, 9)
+        ctx.set_row_sink(None, 0)
+        rows4, _ = g.scan(1, 50, 3, 9)
+        assert np.array_equal(rows4, rows)
     finally:
+        ctx.set_row_sink(None, 0)
         g.free()
 
 
