@@ -162,10 +162,57 @@ def _scan_whole_fasta(fasta, bed_path, fs, report):
         raise
 
 
+def _gpu_scan_contigs(entries, settings):
+    """scan_fn of multi_gpu.scan_contigs_sharded: this rank's contigs as one resident genome, one scan."""
+    ctx = prf_native.default_context()
+    rows, _stats = ctx.scan([(e.addr, e.length) for e in entries], *settings)
+    return rows if len(rows) else []
+
+
+def _scan_whole_fasta_sharded(fasta, bed_path, fs, report, scan_fn=None):
+    """The same under `python -m torch.distributed.run --nproc-per-node N perfect_repeat_finder.py genome.fa`: one
+    process per GPU, contigs dealt to the ranks longest first, every rank scans its share, ONE gather of the rows
+    (RCCL; PRF_DIST_BACKEND=gloo for CPU tensors), rank 0 writes the BED in FASTA order.  Replaces the reference's
+    interval fan-out over Hail Batch jobs and its `cat | sort | uniq` merge
+    (hail_batch_pipeline/run_hail_batch_pipeline.py:76-77,115-123,151-153) on one node, with exact whole-contig rows."""
+    import torch
+    import torch.distributed as dist
+    import multi_gpu
+    if fs.min_repeats < 2:
+        raise NotImplementedError("min_repeats == 1 is not supported on the GPU path (see _gpu_rows)")
+    backend = os.environ.get("PRF_DIST_BACKEND", "nccl")
+    started_here = not dist.is_initialized()
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if started_here:
+        dist.init_process_group(backend)
+    try:
+        entries = list(fasta)
+        settings = (fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
+        try:
+            rows = multi_gpu.scan_contigs_sharded(entries, settings, scan_fn or _gpu_scan_contigs, dist, torch,
+                                                  "cuda" if backend == "nccl" else "cpu")
+        except prf_native.PrfError as exc:
+            if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
+                raise ValueError(exc.message) from None
+            raise
+        if dist.get_rank() == 0:
+            counts = prf_native.write_bed(bed_path, entries, rows)
+            for e, c in zip(entries, counts):
+                report(e, c)
+        dist.barrier()
+        return dist.get_rank() == 0
+    finally:
+        if started_here:
+            dist.destroy_process_group()
+
+
 def _scan_fasta(args, parser):
     if not args.output_prefix:
         args.output_prefix = re.sub(".fa(sta)?(.gz)?", "", args.input_sequence)   # same unanchored pattern as reference :114
     bed_path = f"{os.path.basename(args.output_prefix)}.bed"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch  # noqa: F401  before libprf.so is loaded: PyTorch brings its own HIP runtime (INTEGRATION.md, load order)
     entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
     if not args.interval:
         # the reference crashes here without --interval (:139); scan every contig whole instead
@@ -173,6 +220,10 @@ def _scan_fasta(args, parser):
             print(f"Processing {entry.name} ({len(entry):,d} bp)")
             print(f"Found {n_rows:,d} repeats")
         _check_settings(args)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:                # one process per GPU: contigs sharded over the ranks
+            if _scan_whole_fasta_sharded(entries, bed_path, args, report):
+                print(f"Wrote results to {bed_path}")
+            return
         _scan_whole_fasta(entries, bed_path, args, report)
         print(f"Wrote results to {bed_path}")
         return

@@ -328,6 +328,24 @@ def scan_fasta_to_bed(ctx, fasta, bed_path, kmin, kmax, min_repeats, min_span, o
     return [int(c) for c in counts], stats
 
 
+def write_bed(bed_path, entries, rows):
+    """BED through libprf's writer (host code) from a numpy row array (start, end, k, contig: 24-byte records, contig =
+    index into entries, sorted as the file should be); returns rows per contig."""
+    import numpy as np
+    lib = load_library()
+    rows = np.ascontiguousarray(rows)
+    assert rows.dtype.itemsize == ctypes.sizeof(_Hit)
+    arr, _keep = _contig_array([(e.addr, e.length) for e in entries])
+    hits = _Hits()
+    hits.rows = ctypes.cast(rows.ctypes.data, ctypes.POINTER(_Hit))
+    hits.n = len(rows)
+    names = (ctypes.c_char_p * max(1, len(entries)))(*[e.name.encode() for e in entries])
+    written = ctypes.c_uint64(0)
+    _check(lib, lib.prf_write_bed(os.fsencode(bed_path), 0, names, arr, len(entries), ctypes.byref(hits), ctypes.byref(written)))
+    counts = np.bincount(rows["contig"], minlength=len(entries)) if len(rows) else np.zeros(len(entries), dtype=np.int64)
+    return [int(c) for c in counts]
+
+
 def plan_describe(kmin, kmax, min_repeats, min_span):
     """Host-only: the fused kernel's work plan for these parameters, as a dict (no GPU needed)."""
     import json

@@ -366,6 +366,17 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
     fs = argparse.Namespace(min_motif_size=1, max_motif_size=50, min_repeats=3, min_span=9)
     want = "".join(f"{name}\t{s}\t{e}\t{m}\n" for name, seq in contigs.items() for s, e, m in prf_oracle.detect_repeats(seq, fs))
     assert open("toy.bed").read() == want and want.count("\n") > 100
+    # the same command under torch.distributed.run with two ranks (both on this GPU, gloo for the gather): contigs
+    # sharded over the ranks, rank 0 writes the BED
+    import subprocess
+    import sys
+    from conftest import PKG
+    env = dict(os.environ, PRF_DIST_BACKEND="gloo", PRF_DEVICE="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", os.path.join(PKG, "perfect_repeat_finder.py"), "-o", "two_ranks",
+                          "toy.fasta"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert open("two_ranks.bed").read() == want and res.stdout.count("Wrote results to two_ranks.bed") == 1
     prf.main(["-min", "2", "-max", "6", "CACACACACACAGGGTTTTTTTTTTT"])
     assert open("repeats.tsv").read() == "start_0based\tend\tmotif\n0\t12\tCA\n"
     assert "Found 1 repeats" in capsys.readouterr().out
