@@ -108,6 +108,75 @@ int prf_fasta_open(const char *path, prf_fasta **out) {
     return PRF_OK;
 }
 
+// One contig only.  With a samtools-style index next to an uncompressed file (path + ".fai": name, length, byte offset,
+// bases per line, bytes per line) the record is read by seeking (what pyfastx's own index gives the reference's
+// fasta[chrom].seq, perfect_repeat_finder.py:130); otherwise the file is parsed and the other records dropped.
+// *out holds one entry, or none if the name is absent.
+int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out) {
+    if (!path || !name || !out) return prf_set_error(PRF_EINVAL, "prf_fasta_open_contig: bad arguments");
+    *out = nullptr;
+    const std::string p(path), want(name);
+    const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+    try {
+        if (!gz) {
+            if (FILE *fi = fopen((p + ".fai").c_str(), "rb")) {
+                char line[4096];
+                unsigned long long len = 0, off = 0, lb = 0, lw = 0;
+                bool found = false;
+                while (fgets(line, sizeof line, fi)) {
+                    char *tab = strchr(line, '\t');
+                    if (!tab) continue;
+                    if ((size_t)(tab - line) == want.size() && memcmp(line, want.data(), want.size()) == 0 &&
+                        sscanf(tab + 1, "%llu\t%llu\t%llu\t%llu", &len, &off, &lb, &lw) == 4) {
+                        found = true;
+                        break;
+                    }
+                }
+                fclose(fi);
+                if (found && lb > 0 && lw >= lb) {
+                    if (FILE *f = fopen(path, "rb")) {
+                        const unsigned long long raw = len + (len / lb + 1) * (lw - lb);
+                        std::string buf(raw, '\0');
+                        bool ok = fseeko(f, (off_t)off, SEEK_SET) == 0;
+                        const size_t got = ok ? fread(&buf[0], 1, raw, f) : 0;
+                        fclose(f);
+                        prf_fasta *fa = new prf_fasta();
+                        fa->names.emplace_back(want);
+                        fa->seqs.emplace_back();
+                        std::string &seq = fa->seqs.back();
+                        seq.reserve(len);
+                        for (size_t i = 0; i < got && seq.size() < len; i++) {
+                            const unsigned char ch = (unsigned char)buf[i];
+                            if (ch == '>') break;  // the index does not match the file
+                            if (ch > ' ') seq += (char)ch;
+                        }
+                        if (seq.size() == len) {
+                            *out = fa;
+                            return PRF_OK;
+                        }
+                        delete fa;  // stale index: fall through to the full parse
+                    }
+                }
+            }
+        }
+        prf_fasta *all = nullptr;
+        const int rc = prf_fasta_open(path, &all);
+        if (rc != PRF_OK) return rc;
+        prf_fasta *fa = new prf_fasta();
+        for (size_t i = 0; i < all->names.size(); i++)
+            if (all->names[i] == want) {
+                fa->names.emplace_back(std::move(all->names[i]));
+                fa->seqs.emplace_back(std::move(all->seqs[i]));
+                break;
+            }
+        delete all;
+        *out = fa;
+        return PRF_OK;
+    } catch (const std::bad_alloc &) {
+        return prf_set_error(PRF_ENOMEM, "prf_fasta_open_contig: out of memory reading %s", path);
+    }
+}
+
 int prf_fasta_count(const prf_fasta *f) { return f ? (int)f->names.size() : 0; }
 
 int prf_fasta_entry(const prf_fasta *f, int i, const char **name, const uint8_t **seq, uint64_t *len) {

@@ -213,8 +213,8 @@ def _scan_fasta(args, parser):
     bed_path = f"{os.path.basename(args.output_prefix)}.bed"
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch  # noqa: F401  before libprf.so is loaded: PyTorch brings its own HIP runtime (load order)
-    entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
     if not args.interval:
+        entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
         # the reference crashes here without --interval (:139); scan every contig whole instead
         def report(entry, n_rows):
             print(f"Processing {entry.name} ({len(entry):,d} bp)")
@@ -233,6 +233,7 @@ def _scan_fasta(args, parser):
     args.interval_chrom = parts[0]
     args.interval_start_0based = int(parts[1])
     args.interval_end = int(parts[2])
+    entries = prf_native.Fasta(args.input_sequence, only=args.interval_chrom)   # one record; by seeking if there is a .fai
     if args.interval_chrom not in entries:
         parser.error(f"Chromosome {args.interval_chrom} not found in the input FASTA file")
     entry = entries[args.interval_chrom]

@@ -58,7 +58,7 @@ class ScanStats(ctypes.Structure):
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
-           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink"]
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -101,6 +101,7 @@ def load_library():
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+        lib.prf_fasta_open_contig.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp)]
         lib.prf_fasta_count.argtypes = [vp]
         lib.prf_fasta_entry.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                         ctypes.POINTER(ctypes.c_uint64)]
@@ -267,10 +268,14 @@ class Fasta:
         def seq(self):
             return ctypes.string_at(self.addr, self.length).decode("ascii", "replace") if self.length else ""
 
-    def __init__(self, path):
+    def __init__(self, path, only=None):
+        """only: read just that record (by seeking, if `path`.fai exists and the file is not compressed)."""
         self.lib = load_library()
         h = ctypes.c_void_p()
-        _check(self.lib, self.lib.prf_fasta_open(os.fsencode(path), ctypes.byref(h)))
+        if only is None:
+            _check(self.lib, self.lib.prf_fasta_open(os.fsencode(path), ctypes.byref(h)))
+        else:
+            _check(self.lib, self.lib.prf_fasta_open_contig(os.fsencode(path), only.encode(), ctypes.byref(h)))
         self._h = h
         self.entries = []
         for i in range(self.lib.prf_fasta_count(h)):

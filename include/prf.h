@@ -150,6 +150,9 @@ int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_ro
  * Plain or gzip-compressed files. */
 typedef struct prf_fasta prf_fasta;
 int prf_fasta_open(const char *path, prf_fasta **out);
+/* One record only (reference fasta[chrom].seq, :130): read by seeking if an uncompressed file has a samtools-style
+ * index path + ".fai" next to it, else parsed and filtered.  *out holds one entry, or none if the name is absent. */
+int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out);
 int prf_fasta_count(const prf_fasta *f);
 int prf_fasta_entry(const prf_fasta *f, int i, const char **name, const uint8_t **seq, uint64_t *len);
 void prf_fasta_close(prf_fasta *f);

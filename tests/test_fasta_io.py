@@ -87,3 +87,41 @@ def test_bed_and_tsv_writers_match_the_reference_format(tmp_path):
     # a row that does not fit its contig is refused
     bad = (prf_native._Hit * 1)(prf_native._Hit(10, 20, 5, 1))   # contig 1 is empty
     assert lib.prf_write_bed(bed.encode(), 0, cnames, contigs, len(seqs), ctypes.byref(prf_native._Hits(bad, 1)), None) == prf_native.PRF_EINVAL
+
+
+def test_single_record_access_with_and_without_an_index(tmp_path):
+    """prf_fasta_open_contig: by seeking through a samtools-style .fai, by parsing without one, from gzip, with a
+    stale index, and an absent name."""
+    import gzip
+    import prf_native
+    recs = {"chr1": "ACGT" * 50 + "N" * 7, "chrEmptyLine": "acgtn" * 31, "chr2 desc": "G" * 1, "chr3": "TTAGGG" * 40}
+    path = tmp_path / "g.fa"
+    fai = []
+    with open(path, "wb") as f:
+        for header, seq in recs.items():
+            f.write(f">{header}\n".encode())
+            off = f.tell()
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60].encode() + b"\n")
+            fai.append(f"{header.split()[0]}\t{len(seq)}\t{off}\t60\t61\n")
+    names = {h.split()[0]: s for h, s in recs.items()}
+
+    def fetch(p, name):
+        fa = prf_native.Fasta(str(p), only=name)
+        return [(e.name, e.seq) for e in fa]
+    for name, seq in names.items():                      # no index: parse and filter
+        assert fetch(path, name) == [(name, seq)]
+    assert fetch(path, "chrNope") == []
+    with open(str(path) + ".fai", "wt") as f:
+        f.writelines(fai)
+    for name, seq in names.items():                      # with the index: seek
+        assert fetch(path, name) == [(name, seq)]
+    assert fetch(path, "chrNope") == []
+    with open(str(path) + ".fai", "wt") as f:            # stale index (wrong offsets): detected, falls back to parsing
+        f.writelines(line.replace("\t60\t61", "\t50\t51") for line in fai)
+    for name, seq in names.items():
+        assert fetch(path, name) == [(name, seq)]
+    gz = tmp_path / "g.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(path, "rb").read())
+    assert fetch(gz, "chr3") == [("chr3", names["chr3"])]

@@ -30,8 +30,12 @@ def make_contig(n):
     return bytes(seq[:n])
 
 t_end = time.time() + budget
+t_report = time.time() + 60
 cases = bad = 0
 while time.time() < t_end:
+    if time.time() > t_report:   # a line a minute: a silent job looks hung to the GPU runner
+        print(f'... {cases} scans so far, {bad} mismatches', flush=True)
+        t_report = time.time() + 60
     contigs = [make_contig(rng.choice([0, 1, 50, 3000, 70000, 200000, 400000])) for _ in range(rng.randint(1, 4))]
     kmax_all = rng.choice([6, 20, 50, 100, 150])
     g = ctx.load(contigs, kmax_all)
