@@ -6,9 +6,15 @@
 //    record's lines joined, case preserved.  Plain or gzip-compressed text (zlib reads both).
 //  * prf_write_bed / prf_write_tsv: the reference's output lines, "chrom\tstart\tend\tmotif\n"
 //    (:148-149) and "start_0based\tend\tmotif" + rows (:166-170), motif = seq.upper()[start:start+k].
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -18,24 +24,143 @@
 
 int prf_set_error(int code, const char *fmt, ...);  // api.cpp
 
-struct prf_fasta {
-    std::vector<std::string> names;
-    std::vector<std::string> seqs;
+// sequence bytes: malloc'ed, never zero-filled, always 8 bytes of slack behind size() for word-wide stores
+struct prf_seq {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    prf_seq() = default;
+    prf_seq(prf_seq &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    prf_seq &operator=(prf_seq &&o) noexcept {
+        if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; }
+        return *this;
+    }
+    prf_seq(const prf_seq &) = delete;
+    prf_seq &operator=(const prf_seq &) = delete;
+    ~prf_seq() { free(p); }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        char *q = (char *)realloc(p, want + 8);
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = want;
+    }
+    void room(size_t more) {
+        if (n + more > cap) reserve(std::max(n + more, cap + cap / 2 + 4096));
+    }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
 };
 
+struct prf_fasta {
+    std::vector<std::string> names;
+    std::vector<prf_seq> seqs;
+};
+
+// Copies [p, q) behind s without the bytes <= ' ' (newlines, a '\r' before them, blanks): eight bytes at a time
+// where a word holds none of them, else byte by byte without a branch.
+static inline void append_clean(prf_seq &s, const char *p, const char *q) {
+    s.room((size_t)(q - p));
+    char *out = s.p + s.n;
+    const uint64_t ones = 0x0101010101010101ull;
+    while (q - p >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        if (((w - ones * 0x21u) & ~w & (ones * 0x80u)) == 0) {  // no byte below 0x21
+            memcpy(out, &w, 8);
+            out += 8;
+            p += 8;
+        } else {
+            for (int i = 0; i < 8; i++) {
+                const char c = p[i];
+                *out = c;
+                out += (unsigned char)c > ' ';
+            }
+            p += 8;
+        }
+    }
+    for (; p < q; p++) {
+        *out = *p;
+        out += (unsigned char)*p > ' ';
+    }
+    s.n = (size_t)(out - s.p);
+}
+
 extern "C" {
+
+static inline void add_record(prf_fasta *fa, const char *h, const char *hend) {
+    const char *a = h;  // name = header text up to the first white space
+    while (a < hend && *a != ' ' && *a != '\t' && *a != '\r') a++;
+    fa->names.emplace_back(h, (size_t)(a - h));
+    fa->seqs.emplace_back();
+}
+
+// uncompressed file, mapped: records located first (a '>' at the start of a line), so that every sequence is
+// reserved once at (nearly) its final size and each line is one bounded copy
+static void parse_mapped(prf_fasta *fa, const char *base, size_t n) {
+    const char *end = base + n;
+    std::vector<const char *> heads;
+    for (const char *p = base; p < end;) {
+        const char *g = (const char *)memchr(p, '>', (size_t)(end - p));
+        if (!g) break;
+        if (g == base || g[-1] == '\n') heads.push_back(g);
+        p = g + 1;
+    }
+    for (size_t i = 0; i < heads.size(); i++) {
+        const char *h = heads[i] + 1, *rec_end = i + 1 < heads.size() ? heads[i + 1] : end;
+        const char *nl = (const char *)memchr(h, '\n', (size_t)(rec_end - h));
+        add_record(fa, h, nl ? nl : rec_end);
+        if (!nl) continue;
+        prf_seq &seq = fa->seqs.back();
+        seq.reserve((size_t)(rec_end - nl));
+        append_clean(seq, nl + 1, rec_end);
+    }
+}
 
 int prf_fasta_open(const char *path, prf_fasta **out) {
     if (!path || !out) return prf_set_error(PRF_EINVAL, "prf_fasta_open: bad arguments");
     *out = nullptr;
-    gzFile f = gzopen(path, "rb");
-    if (!f) return prf_set_error(PRF_EINVAL, "prf_fasta_open: cannot open %s", path);
-    gzbuffer(f, 1 << 20);
     prf_fasta *fa = new (std::nothrow) prf_fasta();
-    if (!fa) {
-        gzclose(f);
-        return prf_set_error(PRF_ENOMEM, "prf_fasta_open: out of memory");
+    if (!fa) return prf_set_error(PRF_ENOMEM, "prf_fasta_open: out of memory");
+    try {
+        // plain text: map the file (no copy through zlib's buffers)
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) {
+            delete fa;
+            return prf_set_error(PRF_EINVAL, "prf_fasta_open: cannot open %s", path);
+        }
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool is_file = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+        const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (is_file && !gz) {
+            if (st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    parse_mapped(fa, (const char *)m, (size_t)st.st_size);
+                    munmap(m, (size_t)st.st_size);
+                    close(fd);
+                    *out = fa;
+                    return PRF_OK;
+                }
+            } else {
+                close(fd);
+                *out = fa;
+                return PRF_OK;
+            }
+        }
+        close(fd);
+    } catch (const std::bad_alloc &) {
+        delete fa;
+        return prf_set_error(PRF_ENOMEM, "prf_fasta_open: out of memory reading %s", path);
     }
+    // gzip (or not a regular file): stream through zlib
+    gzFile f = gzopen(path, "rb");
+    if (!f) {
+        delete fa;
+        return prf_set_error(PRF_EINVAL, "prf_fasta_open: cannot open %s", path);
+    }
+    gzbuffer(f, 1 << 20);
     try {
         std::vector<char> buf(1 << 22);
         bool in_header = false, at_line_start = true, have_record = false;
@@ -57,11 +182,7 @@ int prf_fasta_open(const char *path, prf_fasta **out) {
                     const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
                     header.append(p, nl ? nl : end);
                     if (!nl) break;
-                    // name = text after '>' up to the first white space
-                    size_t a = 0;
-                    while (a < header.size() && header[a] != ' ' && header[a] != '\t' && header[a] != '\r') a++;
-                    fa->names.emplace_back(header.substr(0, a));
-                    fa->seqs.emplace_back();
+                    add_record(fa, header.data(), header.data() + header.size());
                     have_record = true;
                     header.clear();
                     in_header = false;
@@ -73,31 +194,13 @@ int prf_fasta_open(const char *path, prf_fasta **out) {
                 } else {
                     const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
                     const char *stop = nl ? nl : end;
-                    if (have_record) {
-                        const char *q = stop;
-                        while (q > p && (unsigned char)q[-1] <= ' ') q--;  // trailing \r / blanks of the line
-                        std::string &s = fa->seqs.back();
-                        // inner white space (rare) is dropped as well
-                        const char *r = p;
-                        while (r < q) {
-                            const char *w = r;
-                            while (w < q && (unsigned char)*w > ' ') w++;
-                            s.append(r, w);
-                            r = w;
-                            while (r < q && (unsigned char)*r <= ' ') r++;
-                        }
-                    }
+                    if (have_record) append_clean(fa->seqs.back(), p, stop);
                     at_line_start = nl != nullptr;
                     p = nl ? nl + 1 : end;
                 }
             }
         }
-        if (in_header) {  // header without a newline at the end of the file
-            size_t a = 0;
-            while (a < header.size() && header[a] != ' ' && header[a] != '\t' && header[a] != '\r') a++;
-            fa->names.emplace_back(header.substr(0, a));
-            fa->seqs.emplace_back();
-        }
+        if (in_header) add_record(fa, header.data(), header.data() + header.size());  // header without a newline at the end of the file
     } catch (const std::bad_alloc &) {
         gzclose(f);
         delete fa;
@@ -143,13 +246,11 @@ int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out) {
                         prf_fasta *fa = new prf_fasta();
                         fa->names.emplace_back(want);
                         fa->seqs.emplace_back();
-                        std::string &seq = fa->seqs.back();
-                        seq.reserve(len);
-                        for (size_t i = 0; i < got && seq.size() < len; i++) {
-                            const unsigned char ch = (unsigned char)buf[i];
-                            if (ch == '>') break;  // the index does not match the file
-                            if (ch > ' ') seq += (char)ch;
-                        }
+                        prf_seq &seq = fa->seqs.back();
+                        size_t stop = 0;  // a '>' inside the span: the index does not match the file
+                        while (stop < got && buf[stop] != '>') stop++;
+                        append_clean(seq, buf.data(), buf.data() + stop);
+                        if (seq.n > len) seq.n = len;
                         if (seq.size() == len) {
                             *out = fa;
                             return PRF_OK;

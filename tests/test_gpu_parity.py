@@ -249,6 +249,30 @@ def test_config_c5_share_random_1250mbp_motif_1_100(ctx):
         g.free()
 
 
+def test_full_size_properties_translation_and_reverse_complement(ctx):
+    """Size-independent properties at BASELINE C2's full size (no oracle needed, so they also run where the oracle
+    would take minutes): (1) translation -- the same contig behind 12 345 + 31 leading N has the same rows, shifted;
+    every position changes its tile, stream, row and bit, so this is a test of all edge handling at once; (2) the
+    rows of the reverse complement are the mirror image (maximal runs, thresholds and primitivity are symmetric;
+    the motif text differs, the (start, end, k) set may not)."""
+    import synth
+    seq = synth.chr_standin().tobytes()
+    n = len(seq)
+    base, _ = ctx.scan([seq], 1, 50, 3, 9)
+    assert len(base) > 50_000
+    pad = 12_345 + 31
+    moved, _ = ctx.scan([b"N" * pad + seq], 1, 50, 3, 9)
+    assert len(moved) == len(base)
+    assert np.array_equal(moved["start"], base["start"] + pad) and np.array_equal(moved["end"], base["end"] + pad)
+    assert np.array_equal(moved["k"], base["k"])
+    comp = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+    rc, _ = ctx.scan([seq.translate(comp)[::-1]], 1, 50, 3, 9)
+    mirror = np.zeros(len(base), dtype=base.dtype)
+    mirror["start"], mirror["end"], mirror["k"] = n - base["end"], n - base["start"], base["k"]
+    mirror = mirror[np.lexsort((mirror["end"], mirror["start"]))]
+    assert np.array_equal(rc, mirror)
+
+
 HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
              133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
              58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569, 0, 4262]
