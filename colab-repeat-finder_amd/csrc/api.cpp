@@ -91,7 +91,6 @@ struct prf_genome {
     u64 nwords = 0;      // G / 64
     u64 padw = 0;        // readable words past nwords in every linear plane
     u32 kmax_hint = 0;
-    u64 serial = 0;      // unique per loaded genome
     u64 *H = nullptr, *L = nullptr, *X = nullptr;  // point PRF_FRONT_PAD words into their allocations
     u64 *d_base = nullptr;
     prf_vplanes vp;      // bit-sliced copy for scan_vertical
@@ -127,6 +126,10 @@ int prf_open(int device_id, prf_ctx **out) {
     prf_ctx *c = new (std::nothrow) prf_ctx();
     if (!c) return fail(PRF_ENOMEM, "prf_open: out of host memory");
     c->dev = device_id;
+    struct guard_t {  // a failure below must not leak the half-built context
+        prf_ctx *c;
+        ~guard_t() { if (c) prf_close(c); }
+    } guard{c};
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
     for (auto &ev : c->ring) HIPCHK(hipEventCreate(&ev));
@@ -135,6 +138,7 @@ int prf_open(int device_id, prf_ctx **out) {
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0));
     HIPCHK(hipMalloc((void **)&c->d_vcounters, 2 * PRF_CNT_N * sizeof(u64)));
     HIPCHK(hipMemset(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64)));
+    guard.c = nullptr;
     *out = c;
     return PRF_OK;
 }
@@ -189,9 +193,7 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
         prf_genome *g;
         ~guard_t() { if (g) prf_genome_free(g); }
     } guard{g};
-    static u64 next_serial = 1;
     g->ctx = c;
-    g->serial = __atomic_fetch_add(&next_serial, 1, __ATOMIC_RELAXED);
     g->kmax_hint = kmax_hint;
     const u64 gap = (u64)kmax_hint + 64;
     u64 cur = 0;
