@@ -65,6 +65,7 @@ struct prf_ctx {
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
+    int n_cus = 256;
     u32 parity = 0;
     u64 scan_seq = 0;
     // generic path scratch
@@ -126,6 +127,7 @@ int prf_open(int device_id, prf_ctx **out) {
     prf_ctx *c = new (std::nothrow) prf_ctx();
     if (!c) return fail(PRF_ENOMEM, "prf_open: out of host memory");
     c->dev = device_id;
+    if (prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     struct guard_t {  // a failure below must not leak the half-built context
         prf_ctx *c;
         ~guard_t() { if (c) prf_close(c); }
@@ -427,7 +429,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             // the counters to the host through mapped memory and clears the counter block of the next scan
             hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
             HIPCHK(hipEventRecord(ev_a, c->stream));
-            HIPCHK(prf_vertical_launch(c->stream, a));
+            HIPCHK(prf_vertical_launch(c->stream, a, c->n_cus));
             HIPCHK(hipEventRecord(ev_b, c->stream));
             // The scan is over for the host when the last workgroup has posted the counter block and this scan's
             // serial number in mapped host memory: poll that word instead of waiting for the stream to drain

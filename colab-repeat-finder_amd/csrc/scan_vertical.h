@@ -67,6 +67,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
 // ASCII (global coordinate space, G bytes) -> bit-sliced planes + tile classes + tile lists. Synchronises the stream.
 int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp);
 
-hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args);
+// n_cus: compute units of the device (picks the register budget: one round of workgroups at 3 per CU, or 4 per CU)
+hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args, int n_cus);
 
 

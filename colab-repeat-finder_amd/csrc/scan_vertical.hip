@@ -79,7 +79,9 @@ __device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
     return (pos >> 3) | (kind << 37) | ((u64)k << 39) | ((u64)mask << 48);
 }
 
-// dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: 3*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64][cof: COF_WORDS u32]
+// dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: P*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
+// [cof: COF_WORDS u32].  P = 3: 48.3 KB, 3 workgroups per CU.  P = 2: the third plane of a tile with N in reach overlays
+// lin, 39.9 KB, 4 workgroups per CU.
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
 constexpr int SMEM_HDR = 192;
 
@@ -95,6 +97,7 @@ struct TileCtx {
     u32 min_repeats, min_span;
     u32 lin_off;              // byte offset of the linear window in LDS
     u32 x_in_lds;             // the window holds X too
+    u32 has_lin;              // the linear window is staged (clean tiles)
 #ifdef PRF_STAMPS
     u64 *dbg;
 #endif
@@ -193,7 +196,7 @@ __device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u
     prf_window_view view;
     view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
     view.w0 = tc.w0;
-    view.nwords = LW;
+    view.nwords = tc.has_lin ? LW : 0;  // 0: every look goes to the global planes
     view.xz_lo = tc.xz_lo;
     view.xz_hi = tc.xz_hi;
     view.x_in_lds = tc.x_in_lds;
@@ -293,6 +296,7 @@ struct Emit {
     int lane;
     prf_lds_cu32 *lin_h, *lin_l;  // the linear window in LDS
     u32 win_q;           // window position of the lane's first stream: 64 + lane*32
+    bool filter;         // the tile has a linear window: echo filter on
 
     // Exact tasks.  Like push(), plus the echo filter: a candidate at position t says that [t, t+M+k) has period
     // k and holds no N.  If the M positions from t on ALSO all match at a shift d < k, then [t, t+M+d) has both
@@ -312,7 +316,7 @@ struct Emit {
                     constexpr int i = decltype(ic)::value;
                     mask |= ((c[i] >> b) & 1u) << i;
                 });
-                if (k > 1) {  // wave-uniform
+                if (k > 1 && filter) {  // wave-uniform
                     const u32 q0 = win_q + b * (64u * T) + (u32)row;
                     const u32 wh = look32(lin_h, q0), wl = look32(lin_l, q0);
                     mask &= ~ones_run<M>(~((wh ^ (wh >> 1)) | (wl ^ (wl >> 1))));
@@ -589,11 +593,18 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &pl
 
 // Grid: first 4 workgroups per tile with N in reach (the 3-plane variant is slower, so each takes one of the
 // four 8-row blocks and they start first), then one workgroup per clean tile.
-template <int NC>
-__global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_args g) {
+// OCC = workgroups per CU the registers are budgeted for.  39.9 KB of LDS allow 4; at 4 the compiler has 128 VGPRs
+// instead of 168 and spills a little (measured: 9-11 % faster on multi-round launches, 3 % slower per workgroup), so
+// launches that fit one round at 3 per CU take the OCC = 3 build.
+template <int NC, int OCC>
+__global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr int nc = NC;
     uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem + SMEM_HDR);
-    const u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)3 * RG * nc * sizeof(uint4));
+    // OCC == 4 (39.9 KB): the third (not-ACGT) plane of a tile with N in reach lies where a clean tile keeps its
+    // linear window; such a tile then verifies on the global planes and takes no echo filter.  OCC == 3 (48.3 KB,
+    // one-round launches, where the slowest workgroup sets the kernel time): room for both.
+    constexpr int LDS_PLANES = OCC >= 4 ? 2 : 3;
+    const u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)LDS_PLANES * RG * nc * sizeof(uint4));
     u64 *lin = reinterpret_cast<u64 *>(prf_smem + lin_off);
     u64 *recs = lin + 2 * LW;
     u32 *rec_cnt = smem_rec_cnt();
@@ -664,11 +675,13 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
                 vimg[(2 * RG + rg) * nc + l] = vx0;
                 vimg[(2 * RG + rg + 4) * nc + l] = vx1;
             }
-            static_for<0, NLF>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                lin[tid + i * NTH] = lw[i];
-            });
-            if (tid < NLT) lin[NLF * NTH + tid] = lt;
+            if (LDS_PLANES == 3 || !hasx) {
+                static_for<0, NLF>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    lin[tid + i * NTH] = lw[i];
+                });
+                if (tid < NLT) lin[NLF * NTH + tid] = lt;
+            }
             if (tid < n_extra) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
                 const int p = tid / (RG * extra), erg = (tid / extra) % RG, el = tid % extra;
                 uint4 r;
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
                     vimg[(p * RG + rg) * nc + 64 + l] = r;
                 }
             }
-            for (int idx = tid; idx < 2 * LW; idx += nt) {
+            for (int idx = tid; idx < ((LDS_PLANES == 2 && hasx) ? 0 : 2 * LW); idx += nt) {
                 const int p = idx / LW, j = idx % LW;
                 lin[idx] = (p == 0 ? g.H : g.L)[w0 + j];
             }
@@ -720,6 +733,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
             tc.min_span = g.min_span;
             tc.lin_off = lin_off;
             tc.x_in_lds = 0u;
+            tc.has_lin = (LDS_PLANES == 2 && hasx) ? 0u : 1u;
 #ifdef PRF_STAMPS
             tc.dbg = g.dbg;
 #endif
@@ -742,6 +756,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 3) void prf_vscan_kernel(prf_vscan_
     em.lin_h = (prf_lds_cu32 *)(prf_smem + lin_off);
     em.lin_l = em.lin_h + 2 * LW;
     em.win_q = 64u + (u32)lane * T;
+    em.filter = LDS_PLANES == 3 || !hasx;
 #ifdef PRF_STAMPS
     u64 *task_dbg = g.dbg ? g.dbg + ((u64)blockIdx.x * MAX_WAVES + wave) * 16 : nullptr;
 #else
@@ -955,16 +970,22 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     return true;
 }
 
-hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
+hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args, int n_cus) {
     const u32 n = args.n_clean + 4u * args.n_mixed;
     if (n == 0) return hipSuccess;
     const dim3 grid(n), block(64 * args.plan.n_waves);
+    const bool one_round = n <= 3u * (u32)n_cus;
+    const u32 lds4 = args.plan.lds_bytes - (u32)((size_t)RG * args.plan.nc * sizeof(uint4));  // the third plane overlays the window
+#define PRF_LAUNCH(NC)                                                                                              \
+    if (one_round) hipLaunchKernelGGL((prf_vscan_kernel<NC, 3>), grid, block, args.plan.lds_bytes, s, args);        \
+    else hipLaunchKernelGGL((prf_vscan_kernel<NC, 4>), grid, block, lds4, s, args)
     switch (args.plan.nc) {
-        case 66: hipLaunchKernelGGL(prf_vscan_kernel<66>, grid, block, args.plan.lds_bytes, s, args); break;
-        case 72: hipLaunchKernelGGL(prf_vscan_kernel<72>, grid, block, args.plan.lds_bytes, s, args); break;
-        case 80: hipLaunchKernelGGL(prf_vscan_kernel<80>, grid, block, args.plan.lds_bytes, s, args); break;
+        case 66: PRF_LAUNCH(66); break;
+        case 72: PRF_LAUNCH(72); break;
+        case 80: PRF_LAUNCH(80); break;
         default: return hipErrorInvalidValue;
     }
+#undef PRF_LAUNCH
     return hipGetLastError();
 }
 
