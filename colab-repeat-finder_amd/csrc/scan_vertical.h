@@ -36,6 +36,7 @@ struct prf_vplan {
     prf_vtask tasks[PRF_VMAX_TASKS];
     u32 nc;                                     // virtual lanes of the LDS image (64 + extra)
     u32 lds_bytes;
+    u32 cof_words;                              // entries of the cofactor table staged in LDS (covers 0 .. kmax)
 };
 
 // everything the fused kernel needs (passed by value)

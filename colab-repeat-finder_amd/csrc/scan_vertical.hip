@@ -80,7 +80,7 @@ __device__ __forceinline__ u64 make_rec(u64 pos, u64 kind, u32 k, u32 mask) {
 }
 
 // dynamic LDS: [TileCtx][rec_cnt: MAX_WAVES u32][hit_cnt] (192 B) [vimg: P*RG*nc uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
-// [cof: COF_WORDS u32].  P = 3: 48.3 KB, 3 workgroups per CU.  P = 2: the third plane of a tile with N in reach overlays
+// [cof: plan.cof_words u32].  P = 3: 48.3 KB, 3 workgroups per CU.  P = 2: the third plane of a tile with N in reach overlays
 // lin, 39.9 KB, 4 workgroups per CU.
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
 constexpr int SMEM_HDR = 192;
@@ -111,7 +111,7 @@ __device__ __forceinline__ u32 *smem_hit_cnt() { return reinterpret_cast<u32 *>(
 // distinct primes and k/p <= 240).  The motif seq[a:a+k] is primitive iff it has none of these periods
 // (reference consists_of_perfect_repeats, utils/perfect_repeat_tracker.py:108-142, tries every divisor).
 struct CofTable {
-    u32 v[PRF_VMAX_K + 1];
+    u32 v[PRF_VMAX_K + 4];
     constexpr CofTable() : v{} {
         for (u32 k = 2; k <= PRF_VMAX_K; k++) {
             u32 rest = k, packed = 0, n = 0;
@@ -125,7 +125,7 @@ struct CofTable {
     }
 };
 __constant__ const CofTable prf_cof_table{};
-constexpr int COF_WORDS = (PRF_VMAX_K + 1 + 3) & ~3;  // LDS copy behind the candidate lists
+// LDS copy behind the candidate lists: entries 0 .. kmax of the scan, rounded up to 4 words (plan.cof_words)
 
 // ---- lean verification for the common case: a candidate well inside a clean tile ----
 // All looks are 32 positions wide and read the LDS window only (H and L; the not-ACGT plane is known to be
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vsca
         }
         {
             u32 *cof_lds = reinterpret_cast<u32 *>(recs + MAX_WAVES * REC_PER_WAVE);
-            for (int i = tid; i <= (int)PRF_VMAX_K; i += nt) cof_lds[i] = prf_cof_table.v[i];
+            for (int i = tid; i < (int)g.plan.cof_words; i += nt) cof_lds[i] = prf_cof_table.v[i];
         }
         if (tid < 2 * MAX_WAVES + 1 && tid != MAX_WAVES) rec_cnt[tid] = 0;  // list lengths, [MAX_WAVES] = row count, flushed counts
         if (tid == 0) {
@@ -965,8 +965,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     for (u32 w = nw; w <= PRF_VMAX_WAVES; w++) plan->wave_begin[w] = plan->n_tasks;
     const u32 need_nc = 64 + (24 + reach) / T;  // the last block starts at row 24; virtual lanes 64 .. 63+offset
     plan->nc = need_nc <= 66 ? 66 : (need_nc <= 72 ? 72 : 80);  // the widths the kernel is instantiated for
+    plan->cof_words = (kmax + 1 + 3) & ~3u;  // <= PRF_VMAX_K + 4: the table is declared with that many entries
     plan->lds_bytes = (u32)(SMEM_HDR + (size_t)3 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
-                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (size_t)COF_WORDS * sizeof(u32));
+                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (size_t)plan->cof_words * sizeof(u32));
     return true;
 }
 
@@ -974,8 +975,10 @@ hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args, int n_
     const u32 n = args.n_clean + 4u * args.n_mixed;
     if (n == 0) return hipSuccess;
     const dim3 grid(n), block(64 * args.plan.n_waves);
-    const bool one_round = n <= 3u * (u32)n_cus;
     const u32 lds4 = args.plan.lds_bytes - (u32)((size_t)RG * args.plan.nc * sizeof(uint4));  // the third plane overlays the window
+    // the 4-per-CU build only where 4 workgroups fit a CU's 160 KB of LDS (motif sizes up to ~130) and the launch
+    // has more workgroups than 3 per CU can hold at once
+    const bool one_round = n <= 3u * (u32)n_cus || 4u * ((lds4 + 1023u) & ~1023u) > 160u * 1024u;
 #define PRF_LAUNCH(NC)                                                                                              \
     if (one_round) hipLaunchKernelGGL((prf_vscan_kernel<NC, 3>), grid, block, args.plan.lds_bytes, s, args);        \
     else hipLaunchKernelGGL((prf_vscan_kernel<NC, 4>), grid, block, lds4, s, args)
