@@ -190,8 +190,7 @@ __device__ __forceinline__ int fast_candidate(prf_lds_cu32 *h, prf_lds_cu32 *l, 
 // Candidate records -> rows.  only_list >= 0: the records [0, n) of that wave's list, taken by lanes
 // first, first+stride, ... (a wave emptying its own full list in the middle of the scan).  only_list < 0:
 // the records of all lists, as one index space [0, n) (the cooperative pass at the end of the tile).
-// Not inlined: called from two places.
-__device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
+__device__ __forceinline__ void verify_records_impl(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     prf_window_view view;
     view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
@@ -271,6 +270,12 @@ __device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u
         }
 #endif
     }
+}
+
+// A wave emptying its own full list in the middle of the scan: rare, and called from inside every task, so not inlined
+// (a function call: the callee saves the registers it uses to scratch memory).
+__device__ __noinline__ void verify_records(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride) {
+    verify_records_impl(recs, only_list, n, first, stride);
 }
 
 // bit t of the result: bits t .. t+M-1 of z are all ones (M <= 16)
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vsca
         if (n_records)
             atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_records);
     }
-    verify_records((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);
+    verify_records_impl((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)nt);  // inlined: no call, no register saves
     PRF_STAMP(5);
     __syncthreads();
     PRF_STAMP(6);
