@@ -273,6 +273,46 @@ def test_full_size_properties_translation_and_reverse_complement(ctx):
     assert np.array_equal(rc, mirror)
 
 
+def test_multi_round_launch_with_n_blocks_takes_the_four_per_cu_build(ctx):
+    """More than 768 tiles -> the 4-workgroups-per-CU build of the fused kernel, in which a tile with N in reach keeps its
+    not-ACGT plane where clean tiles keep their linear window and verifies on the global planes.  70 Mbp stand-in with
+    N blocks of many sizes sprinkled in (tile-aligned, straddling tile edges, single N): fused == generic row for row,
+    and the oracle on windows around N-block edges."""
+    import prf_native
+    import synth
+    from oracle import prf_oracle
+    n = 70_000_000
+    seq = bytearray(synth.chr_standin(length=n, seed=77, n_head=1_000_000, n_tail=5_000, repeats_per_mbp=2500).tobytes())
+    rng = np.random.default_rng(5)
+    blocks = []
+    for i in range(60):
+        p = int(rng.integers(1_100_000, n - 200_000))
+        ln = int(rng.choice([1, 2, 7, 50, 1000, 65_536, 100_000]))
+        if i % 5 == 0:
+            p = (p // 65_536) * 65_536 - int(rng.integers(0, 3))      # at / just before a tile edge
+        seq[p:p + ln] = b"N" * ln
+        blocks.append((p, ln))
+    for p, ln in blocks[:20]:                                            # repeats that run into an N block, or out of one
+        seq[p - 30:p] = (b"CAG" * 10)
+        seq[p + ln:p + ln + 24] = (b"AT" * 12)
+    seq = bytes(seq)
+    g = ctx.load([seq], 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and len(rows) > 100_000
+        rows2, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert st2.path == 0 and np.array_equal(rows, rows2)
+        starts, ends, ks = rows["start"].astype(np.int64), rows["end"].astype(np.int64), rows["k"].astype(np.int64)
+        for p, ln in blocks[:12]:
+            lo, hi = max(0, p - 150_000), min(n, p + ln + 150_000)
+            want = [(s + lo, e + lo, k) for s, e, _m, k in prf_oracle.detect_rows(seq[lo:hi], 1, 50, 3, 9)
+                    if s >= 1_000 and e <= hi - lo - 1_000]
+            sel = (starts >= lo + 1_000) & (ends <= hi - 1_000)
+            assert list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist())) == want, (p, ln)
+    finally:
+        g.free()
+
+
 HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
              133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
              58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569, 0, 4262]
