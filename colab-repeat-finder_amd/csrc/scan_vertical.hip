@@ -402,6 +402,13 @@ __device__ __forceinline__ const uint4 *slot_of(const uint4 *lane_base, int gg) 
     return lane_base + ((gg & 7) * NC + (gg >> 3));
 }
 
+// Slot g (compile-time) after a run-time first slot gg0 whose address `first` = slot_of(lane_base, gg0) and
+// a = gg0 & 7 are computed once per block: the stream wraps into the next virtual lane at most once within a block.
+template <int NC, int G>
+__device__ __forceinline__ const uint4 *slot_after(const uint4 *first, int a) {
+    return first + G * NC + (a + G >= 8 ? 1 - 8 * NC : 0);
+}
+
 // ---- group task: motif sizes k0 .. k0+7 (those in `valid`), the 8-row blocks tb0 .. tb1-1 of the stream ----
 template <bool HASX, int NC>
 __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, u32 valid, u32 stride, int tb0, int tb1, Emit &em) {
@@ -426,9 +433,11 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, 
             unpack4(&a[p][4], pa[p * PS + NC]);
         });
         const int g0 = 2 * tb + (int)(k0 >> 2);
+        const uint4 *pw0 = slot_of<NC>(lane_base, g0);
+        const int wa = g0 & 7;
         static_for<0, 4>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const uint4 *pw = slot_of<NC>(lane_base, g0 + g);
+            const uint4 *pw = slot_after<NC, g>(pw0, wa);
             static_for<0, NP>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 unpack4(&w[p][4 * g], pw[p * PS]);
@@ -514,9 +523,12 @@ __device__ __forceinline__ void exact_task(const uint4 *vimg, int lane, u32 k, i
         u32 a[3][4 * NGB];
         u32 s[3][4 * NGS];
         const int gs0 = 2 * tb + (int)(k >> 2);
+        const uint4 *pb0 = lane_base + 2 * tb * NC;  // slot 2*tb < 8: no wrap yet
+        const uint4 *ps0 = slot_of<NC>(lane_base, gs0);
+        const int ba = 2 * tb, sa = gs0 & 7;
         static_for<0, NGB>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const uint4 *pb = slot_of<NC>(lane_base, 2 * tb + g);
+            const uint4 *pb = slot_after<NC, g>(pb0, ba);
             static_for<0, NP>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 unpack4(&a[p][4 * g], pb[p * PS]);
@@ -524,7 +536,7 @@ __device__ __forceinline__ void exact_task(const uint4 *vimg, int lane, u32 k, i
         });
         static_for<0, NGS>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const uint4 *pw = slot_of<NC>(lane_base, gs0 + g);
+            const uint4 *pw = slot_after<NC, g>(ps0, sa);
             static_for<0, NP>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 unpack4(&s[p][4 * g], pw[p * PS]);
