@@ -349,7 +349,7 @@ struct Emit {
     // 8-row group starting at `row`; bit b of c[i] set = it reports for motif size k0+i.  One record per (stream,
     // motif size): a record that named several sizes would be verified by one lane, size after size, while the
     // other lanes of its wave wait.
-    __device__ __forceinline__ void push(u32 hot, const u32 (&c)[8], int row, u64 kind, u32 k0) {
+    __device__ __forceinline__ void push(u32 hot, const u32 (&c)[8], int row, u64 kind, u32 k0, u32 valid) {
         u32 mask = 0, b = 0;
         while (__builtin_amdgcn_ballot_w64((hot | mask) != 0) != 0) {
             if (mask == 0 && hot) {
@@ -359,6 +359,7 @@ struct Emit {
                     constexpr int i = decltype(ic)::value;
                     mask |= ((c[i] >> b) & 1u) << i;
                 });
+                mask &= valid;  // motif sizes of the chunk that are outside the scan's range
             }
             const u64 bal = __builtin_amdgcn_ballot_w64(mask != 0);
             const u32 n = (u32)__builtin_popcountll(bal);
@@ -410,7 +411,9 @@ __device__ __forceinline__ const uint4 *slot_after(const uint4 *first, int a) {
 }
 
 // ---- group task: motif sizes k0 .. k0+7 (those in `valid`), the 8-row blocks tb0 .. tb1-1 of the stream ----
-template <bool HASX, int NC>
+// S1: every block is examined (stride 1) and a group reports only if the group before it was not all-match; otherwise
+// (stride 2 / 4) every examined all-match group reports.
+template <bool HASX, int NC, bool S1>
 __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, u32 valid, u32 stride, int tb0, int tb1, Emit &em) {
     constexpr int NP = HASX ? 3 : 2;
     constexpr int PS = RG * NC;  // slots per plane
@@ -444,7 +447,7 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, 
             });
         });
         // All 8 motif sizes are computed in one straight-line block so that their 8 independent OR chains
-        // interleave (a chain alone is 16 dependent operations); sizes outside `valid` are masked at the end.
+        // interleave (a chain alone is 16 dependent operations); sizes outside `valid` are dropped when records are made.
         u32 cand[8];
         u32 hot = 0;
         static_for<0, 8>([&](auto kc) {
@@ -463,13 +466,16 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, int lane, u32 k0, 
                     o = o | a[2][i] | w[2][kk + i];
                 });
             }
-            const u32 vm = ((valid >> kk) & 1u) ? ~0u : 0u;  // wave-uniform
-            const u32 c = ~o & prev[kk] & vm;  // all 8 rows match, the previous group did not (or is unknown)
-            prev[kk] = stride == 1 ? o : ~0u;
+            u32 c = ~o;  // all 8 rows match ...
+            if constexpr (S1) {
+                c &= prev[kk];  // ... and the previous group did not (or is unknown: first block)
+                prev[kk] = o;
+            }
             cand[kk] = c;
             hot |= c;
         });
-        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, kind, k0);
+
+        if (__builtin_amdgcn_ballot_w64(hot != 0) != 0) em.push(hot, cand, 8 * tb, kind, k0, valid);
     }
 }
 
@@ -589,7 +595,10 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const prf_vplan &pl
         if (dbg && lane == 0) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
 #endif
         switch (task.kind) {
-            case 0: group_task<HASX, NC>(vimg, lane, task.k0, task.valid, task.stride, tb0, tb1, em); break;
+            case 0:
+                if (task.stride == 1) group_task<HASX, NC, true>(vimg, lane, task.k0, task.valid, 1u, tb0, tb1, em);
+                else group_task<HASX, NC, false>(vimg, lane, task.k0, task.valid, task.stride, tb0, tb1, em);
+                break;
             case 1: exact_task_any<1, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
             case 2: exact_task_any<2, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
             case 3: exact_task_any<3, HASX, NC>(vimg, lane, task.k0, tb0, tb1, em); break;
