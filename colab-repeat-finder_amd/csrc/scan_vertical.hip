@@ -818,24 +818,29 @@ __global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vsca
     // this CU's L1/L2) is copied there.  The order of the ranges is whatever order the workgroups get here in; the
     // host sorts rows after the fetch anyway (reference perfect_repeat_finder.py:81).
     u64 *xch = reinterpret_cast<u64 *>(recs);  // the candidate lists are dead now
+    const u32 n_rows = *hit_cnt;  // final since the barrier above
+    const u32 stored = n_rows < g.hit_cap ? n_rows : g.hit_cap;
     if (tid == 0) {
-        const u32 n = *hit_cnt;
-        const u32 stored = n < g.hit_cap ? n : g.hit_cap;
-        if (n > g.hit_cap) {  // rare: wait for the result, so that the maximum is in place before the ticket is drawn
-            const u64 prev = atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n);
+        if (n_rows > g.hit_cap) {  // rare: wait for the result, so that the maximum is in place before the ticket is drawn
+            const u64 prev = atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
             asm volatile("" ::"v"(prev));
         }
         xch[0] = atomicAdd(&g.counters[PRF_CNT_ROWS], (u64)stored | (1ull << PRF_ROWS_TICKET_SHIFT));
-        xch[1] = stored;
     }
+    // while thread 0 waits for its atomic, everybody reads the first words of the slab (up to 170 rows: all of them
+    // on ordinary sequence); the two memory round trips overlap
+    const u64 *src = reinterpret_cast<const u64 *>(g.hit_slabs + (tile * 4 + part) * (u64)g.hit_cap);
+    const u32 n_words = 3u * stored;
+    const u64 w0 = (u32)tid < n_words ? src[tid] : 0ull;
+    const u64 w1 = (u32)tid + (u32)nt < n_words ? src[tid + nt] : 0ull;
     __syncthreads();
     const u64 base = xch[0] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
     const u64 ticket = xch[0] >> PRF_ROWS_TICKET_SHIFT;
-    const u32 stored = (u32)xch[1];
     if (base + stored <= g.rows_cap) {  // else: the host sees the cursor beyond the capacity, grows the array, rescans
-        const u64 *src = reinterpret_cast<const u64 *>(g.hit_slabs + (tile * 4 + part) * (u64)g.hit_cap);
         u64 *dst = reinterpret_cast<u64 *>(g.rows + base);
-        for (u32 i = (u32)tid; i < 3u * stored; i += (u32)nt) dst[i] = src[i];
+        if ((u32)tid < n_words) dst[tid] = w0;
+        if ((u32)tid + (u32)nt < n_words) dst[tid + nt] = w1;
+        for (u32 i = (u32)tid + 2u * (u32)nt; i < n_words; i += (u32)nt) dst[i] = src[i];
     }
     // ---- 5. the last workgroup to draw a ticket hands the counter block to the host (mapped memory, no copy call)
     // and clears the block of the next scan (no memset call).  The counters are only ever touched by device-scope
