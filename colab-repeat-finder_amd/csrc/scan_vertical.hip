@@ -319,7 +319,7 @@ struct Emit {
                 hot &= hot - 1;
                 static_for<0, 8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    mask |= ((c[i] >> b) & 1u) << i;
+                    mask |= __builtin_amdgcn_ubfe(c[i], b, 1u) << i;  // v_bfe_u32 + v_lshl_or_b32
                 });
                 if (k > 1 && filter) {  // wave-uniform
                     const u32 q0 = win_q + b * (64u * T) + (u32)row;
@@ -357,7 +357,7 @@ struct Emit {
                 hot &= hot - 1;
                 static_for<0, 8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    mask |= ((c[i] >> b) & 1u) << i;
+                    mask |= __builtin_amdgcn_ubfe(c[i], b, 1u) << i;  // v_bfe_u32 + v_lshl_or_b32
                 });
                 mask &= valid;  // motif sizes of the chunk that are outside the scan's range
             }
