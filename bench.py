@@ -74,8 +74,8 @@ def cpu_baseline(seq_bytes, kmin, kmax, min_repeats, min_span, sample_bp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--length", type=int, default=0, help="contig length per GPU (default: chr22, 50 818 468)")
     ap.add_argument("--kmin", type=int, default=1)
     ap.add_argument("--kmax", type=int, default=50)
