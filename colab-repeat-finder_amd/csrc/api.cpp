@@ -76,6 +76,19 @@ struct prf_ctx {
     prf_hit_dev *sink = nullptr;    // caller-owned device array the rows go to instead (prf_set_row_sink)
     u64 sink_cap = 0;
     const prf_hit_dev *last_rows = nullptr;  // where the rows of the last scan are
+    // pipelined scans (prf_scan_genome_async / prf_scan_wait): two slots used alternately, each with its own host
+    // counter block and row array; slot 0 shares them with the synchronous path
+    struct async_slot {
+        u64 seq = 0;            // scan in this slot (0: free)
+        u64 *h = nullptr;       // mapped host counter block (+ serial number word)
+        u64 *h_dev = nullptr;
+        prf_hit_dev *rows = nullptr;
+        u64 positions = 0;
+    } slot[2];
+    u64 async_n = 0;
+    u64 *h_async = nullptr;         // slot 1's counter block
+    prf_hit_dev *d_hits_async = nullptr;
+    u64 hit_cap_async = 0;
     // fused (bit-sliced) path scratch: one row slab per tile
     prf_hit_dev *d_hit_slabs = nullptr;
     u64 slab_tiles = 0;
@@ -151,6 +164,8 @@ void prf_close(prf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_counters);
     (void)hipHostFree(c->h_counters);
+    (void)hipHostFree(c->h_async);
+    (void)hipFree(c->d_hits_async);
     (void)hipFree(c->d_vcounters);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
@@ -292,8 +307,8 @@ int prf_genome_synth(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, in
 }
 
 // poll the serial number the fused kernel's last workgroup writes behind the counter block (mapped host memory)
-static int wait_for_seq(prf_ctx *c, u64 seq) {
-    const u64 *seqp = c->h_counters + PRF_CNT_N;
+static int wait_for_seq(prf_ctx *c, u64 seq, const u64 *block = nullptr) {
+    const u64 *seqp = (block ? block : c->h_counters) + PRF_CNT_N;
     for (u64 spins = 1;; spins++) {
         if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) return PRF_OK;
         __builtin_ia32_pause();
@@ -573,6 +588,106 @@ int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin
     rc = prf_scan_genome(c, g, kmin, kmax, min_repeats, min_span, flags, out, stats);
     prf_genome_free(g);
     return rc;
+}
+
+// ---- pipelined scans: enqueue now, collect later (at most two in flight) ----
+// The launch latency and the host's share of a scan (~9 of ~37 us on the chr22 scan) then overlap the previous
+// scan's kernel: kernels of one stream run back to back.  Fused path only, no row sink, buffers already sized by an
+// ordinary scan of the same genome and parameters; anything else is refused and the caller scans synchronously.
+static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,
+                           uint64_t *seq_out) {
+    if (!c || !g || !seq_out) return fail(PRF_EINVAL, "prf_scan_genome_async: bad arguments");
+    if (g->ctx != c) return fail(PRF_EINVAL, "prf_scan_genome_async: genome belongs to another context");
+    if (c->sink) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: not with a row sink");
+    if (kmin < 1 || kmax < kmin || min_repeats < 2 || min_span < 1 || kmax > g->kmax_hint)
+        return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: parameters the synchronous call would refuse or serve otherwise");
+    prf_vscan_args a;
+    if (!prf_vertical_plan(kmin, kmax, min_repeats, min_span, &a.plan))
+        return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: no fused plan for these parameters");
+    if (g->vp.n_clean + g->vp.n_mixed == 0) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: nothing to launch");
+    const u64 nslabs = (g->G / PRF_TILE - 1) * 4;
+    if (nslabs > c->slab_tiles || c->slab_cap == 0 || c->hit_cap == 0)
+        return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: scan this genome synchronously once first (buffers are sized there)");
+    HIPCHK(hipSetDevice(c->dev));
+    prf_ctx::async_slot &sl = c->slot[c->async_n & 1u];
+    if (sl.seq) return fail(PRF_EINVAL, "prf_scan_genome_async: two scans are in flight already; prf_scan_wait() first");
+    if ((c->async_n & 1u) == 0) {
+        sl.h = c->h_counters; sl.h_dev = c->h_counters_dev; sl.rows = c->d_hits;
+    } else {
+        if (!c->h_async) {
+            HIPCHK(hipHostMalloc((void **)&c->h_async, (PRF_CNT_N + 8) * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+            memset(c->h_async, 0, (PRF_CNT_N + 8) * sizeof(u64));
+        }
+        if (c->hit_cap_async < c->hit_cap) {
+            (void)hipFree(c->d_hits_async);
+            c->d_hits_async = nullptr;
+            c->hit_cap_async = 0;
+            HIPCHK(hipMalloc((void **)&c->d_hits_async, c->hit_cap * sizeof(prf_hit_dev)));
+            c->hit_cap_async = c->hit_cap;
+        }
+        sl.h = c->h_async; sl.rows = c->d_hits_async;
+        if (!sl.h_dev) HIPCHK(hipHostGetDevicePointer((void **)&sl.h_dev, c->h_async, 0));
+    }
+    a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
+    a.H = g->H; a.L = g->L; a.X = g->X;
+    a.tile_list = g->vp.tile_list;
+    a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
+    a.clean_base = g->vp.clean_base;
+    a.hit_slabs = c->d_hit_slabs; a.hit_cap = c->slab_cap;
+    a.rows = sl.rows; a.rows_cap = c->hit_cap; a.count_row = 0;
+    a.min_repeats = min_repeats; a.min_span = min_span;
+    a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
+    a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
+    a.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
+    a.host_counters = sl.h_dev;
+    a.seq = ++c->scan_seq;
+    c->parity ^= 1u;
+    a.dbg = nullptr;
+    hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
+    HIPCHK(hipEventRecord(ev_a, c->stream));
+    HIPCHK(prf_vertical_launch(c->stream, a, c->n_cus));
+    HIPCHK(hipEventRecord(ev_b, c->stream));
+    sl.seq = a.seq;
+    sl.positions = g->positions;
+    c->async_n++;
+    *seq_out = a.seq;
+    return PRF_OK;
+}
+
+int prf_scan_genome_async(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,
+                          uint64_t *seq_out) {
+    try {
+        return scan_async_impl(c, g, kmin, kmax, min_repeats, min_span, seq_out);
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_scan_genome_async: unexpected exception");
+    }
+}
+
+int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
+    if (!c || !seq) return fail(PRF_EINVAL, "prf_scan_wait: bad arguments");
+    prf_ctx::async_slot *sl = c->slot[0].seq == seq ? &c->slot[0] : (c->slot[1].seq == seq ? &c->slot[1] : nullptr);
+    if (!sl) return fail(PRF_EINVAL, "prf_scan_wait: scan %llu is not in flight", (unsigned long long)seq);
+    int rc = wait_for_seq(c, seq, sl->h);
+    sl->seq = 0;
+    if (rc) return rc;
+    const u64 nhits = sl->h[PRF_CNT_ROWS] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+    u64 ncand = 0;
+    for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) ncand += sl->h[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
+    if (sl->h[PRF_CNT_HIT_OVF] > c->slab_cap || nhits > c->hit_cap)
+        return fail(PRF_EUNSUPPORTED, "prf_scan_wait: the buffers sized by the last synchronous scan overflowed; scan synchronously");
+    c->last_nhits = nhits;
+    c->last_rows = sl->rows;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->positions = sl->positions;
+        stats->packed_bytes = (sl->positions + 3) / 4;
+        stats->n_candidates = ncand;
+        stats->n_hits = nhits;
+        stats->n_launches = 1;
+        stats->path = 1;
+        stats->seq = seq;
+    }
+    return PRF_OK;
 }
 
 int prf_set_row_sink(prf_ctx *c, void *dst_device, uint64_t capacity_rows) {

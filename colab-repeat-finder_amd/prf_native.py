@@ -58,7 +58,8 @@ class ScanStats(ctypes.Structure):
 EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", "prf_close", "prf_genome_load",
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
-           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig"]
+           "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
+           "prf_scan_wait"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -98,6 +99,8 @@ def load_library():
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_set_row_sink.argtypes = [vp, vp, ctypes.c_uint64]
+        lib.prf_scan_genome_async.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_scan_wait.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(ScanStats)]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -176,6 +179,13 @@ class Genome:
         finally:
             lib.prf_free_hits(ctypes.byref(hits))
 
+    def scan_async(self, kmin, kmax, min_repeats, min_span):
+        """Enqueue a scan (at most two in flight); returns its serial number for Context.scan_wait()."""
+        seq = ctypes.c_uint64(0)
+        _check(self.ctx.lib, self.ctx.lib.prf_scan_genome_async(self.ctx._h, self._h, kmin, kmax, min_repeats, min_span,
+                                                                 ctypes.byref(seq)))
+        return seq.value
+
     def free(self):
         if self._h is not None:
             self.ctx.lib.prf_genome_free(self._h)
@@ -231,6 +241,12 @@ class Context:
         _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows,
                                                           1 if count_row else 0, ctypes.byref(n)))
         return n.value
+
+    def scan_wait(self, seq):
+        """Collect a scan enqueued with Genome.scan_async(); returns its ScanStats (row and candidate counts)."""
+        stats = ScanStats()
+        _check(self.lib, self.lib.prf_scan_wait(self._h, seq, ctypes.byref(stats)))
+        return stats
 
     def set_row_sink(self, dst_ptr, capacity_rows):
         """Following scans compact their rows into caller-owned device memory (capacity_rows + 1 records, the last

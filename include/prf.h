@@ -123,6 +123,17 @@ int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t k
 int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax,
              uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
 
+/* Pipelined scans.  prf_scan_genome_async() enqueues a scan and returns its serial number at once;
+ * prf_scan_wait() collects it (row count and candidate count in *stats; kernel time through prf_scan_timings;
+ * rows through prf_last_hits_to_device, valid until the next-but-one scan is enqueued).  At most two scans are in
+ * flight, so the launch and the host's share of scan i+1 overlap the kernel of scan i.  Served only where it needs no
+ * decisions on the way: fused path, no row sink, buffers sized by an earlier prf_scan_genome() of the same genome and
+ * parameters; PRF_EUNSUPPORTED otherwise, and from prf_scan_wait() if those buffers overflowed -- scan
+ * synchronously then.  No other call on the context while scans are in flight. */
+int prf_scan_genome_async(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                          uint32_t min_span, uint64_t *seq_out);
+int prf_scan_wait(prf_ctx *ctx, uint64_t seq, prf_scan_stats *stats);
+
 /* Row sink: the rows of the following scans on this context are compacted straight into caller-owned device
  * memory (e.g. the send buffer of an RCCL gather) instead of the library's own array.  dst_device must hold
  * capacity_rows + 1 prf_hit records; record number capacity_rows receives {start = number of rows, 0, 0, 0}.

@@ -388,6 +388,29 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
         got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
         got = got[np.lexsort((got["end"], got["start"], got["contig"]))]
         assert np.array_equal(got, rows)
+        # pipelined scans: two in flight, collected one step late; rows of a collected scan through the hand-off
+        pending, done = None, []
+        for _ in range(7):
+            sq = g.scan_async(1, 50, 3, 9)
+            if pending is not None:
+                done.append(ctx.scan_wait(pending))
+            pending = sq
+        done.append(ctx.scan_wait(pending))
+        assert [int(d.n_hits) for d in done] == [len(rows)] * 7 and [d.seq for d in done] == sorted(d.seq for d in done)
+        assert all(0 < m < 50 for m in ctx.scan_timings(done[0].seq, 7))
+        buf.fill_(-1)
+        torch.cuda.synchronize()
+        assert ctx.last_hits_to_device(buf.data_ptr(), cap) == n
+        got = np.ascontiguousarray(buf.cpu().numpy()[:n]).view(rows.dtype).reshape(-1)
+        assert np.array_equal(got[np.lexsort((got["end"], got["start"], got["contig"]))], rows)
+        with pytest.raises(prf_native.PrfError):
+            a1, a2 = g.scan_async(1, 50, 3, 9), g.scan_async(1, 50, 3, 9)
+            try:
+                g.scan_async(1, 50, 3, 9)                    # a third one in flight is refused
+            finally:
+                ctx.scan_wait(a1), ctx.scan_wait(a2)
+        rows5, _ = g.scan(1, 50, 3, 9)                       # the synchronous path is untouched by all that
+        assert np.array_equal(rows5, rows)
         # row sink: the kernel compacts the rows straight into caller-owned memory, count record behind them;
         # both kernel paths, a fetch through the sink, and a sink that is too small
         for fl in (prf_native.SCAN_DEFAULT, prf_native.SCAN_FORCE_GENERIC):
