@@ -6,7 +6,10 @@
 
 A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: ONE kernel launch (scan +
 verify + compaction of the rows into one array in HBM + counters), row count back on the host -- on a genome
-that is already packed and resident in HBM when the timed region starts.  Workload (BASELINE.json configs[1]): a
+that is already packed and resident in HBM when the timed region starts.  At N = 1 two scans are in flight (prf_scan_genome_async / prf_scan_wait): scan i+1 is
+enqueued before scan i is collected, so its launch and the host's share overlap the kernel of scan i; all K scans
+are collected -- row count on the host, checked -- inside the timed region (--no-pipeline: one at a time).
+Workload (BASELINE.json configs[1]): a
 chr22-sized contig (50 818 468 bp), motif sizes 1-50, min_repeats 3, min_span 9.  No genome FASTA exists
 offline, so the contig is the synthetic stand-in of colab-repeat-finder_amd/synth.py (hg38-like N blocks,
 ~1.8 k planted repeats per Mbp, uniform ACGT elsewhere).
