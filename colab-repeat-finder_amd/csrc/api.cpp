@@ -2,13 +2,15 @@
 //
 // Host-side shape of one scan (what replaces the body of the reference's detect_repeats(),
 // perfect_repeat_finder.py:33-81):
-//   memset counters -> phase 1 kernel(s) (candidates) -> phase 2 kernel (verify + filters + rows)
-//   -> copy back two counters -> (grow buffers and repeat on overflow) -> copy rows back, sort by
-//   (contig, start, end) as the reference sorts its dict (:81).
+//   fused path (kmax <= 480): ONE kernel launch -- scan + verify + rows compacted into one array + counters posted
+//   to mapped host memory; the host polls the scan's serial number there.  Generic path (any k): memset counters ->
+//   candidate kernel -> verify kernel -> copy back two counters.  Either way: grow buffers and repeat on overflow,
+//   then copy the rows back (sorted by (contig, start, end) as the reference sorts its dict, :81).
 // Everything runs on the context's own HIP stream; timings are HIP events on that stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +152,9 @@ int prf_open(int device_id, prf_ctx **out) {
     for (auto &ev : c->ring) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipMalloc((void **)&c->d_counters, PRF_CNT_N * sizeof(u64)));
     HIPCHK(hipHostMalloc((void **)&c->h_counters, (PRF_CNT_N + 8) * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+    // recycled pinned blocks are not zeroed, and the scan serial numbers restart at 1 for every context: a stale
+    // serial number left by a closed context must never look like a finished scan
+    memset(c->h_counters, 0, (PRF_CNT_N + 8) * sizeof(u64));
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0));
     HIPCHK(hipMalloc((void **)&c->d_vcounters, 2 * PRF_CNT_N * sizeof(u64)));
     HIPCHK(hipMemset(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64)));
@@ -306,9 +311,25 @@ int prf_genome_synth(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, in
     }
 }
 
-// poll the serial number the fused kernel's last workgroup writes behind the counter block (mapped host memory)
+// After a fused launch failed or never posted its counters the device-side counter blocks are in an unknown state
+// (the kernel clears the NEXT scan's block only when its last workgroup gets there): drain the stream, clear both.
+static void reset_vcounters(prf_ctx *c) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemsetAsync(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+}
+
+// Poll the serial number the fused kernel's last workgroup writes behind the counter block (mapped host memory).
+// Bounded by the wall clock (PRF_SCAN_TIMEOUT_S, default 120 s): a wedged kernel becomes PRF_EHIP, not a wedged host.
 static int wait_for_seq(prf_ctx *c, u64 seq, const u64 *block = nullptr) {
     const u64 *seqp = (block ? block : c->h_counters) + PRF_CNT_N;
+    static const double limit_s = [] {
+        const char *e = getenv("PRF_SCAN_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
     for (u64 spins = 1;; spins++) {
         if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) return PRF_OK;
         __builtin_ia32_pause();
@@ -316,9 +337,21 @@ static int wait_for_seq(prf_ctx *c, u64 seq, const u64 *block = nullptr) {
             const hipError_t e = hipStreamQuery(c->stream);
             if (e == hipSuccess) {
                 if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == seq) return PRF_OK;
-                return fail(PRF_EHIP, "fused scan kernel finished without posting its counters");
+                reset_vcounters(c);
+                return fail(PRF_EHIP, "fused scan kernel finished without posting its counters (scan %llu)", (unsigned long long)seq);
             }
-            if (e != hipErrorNotReady) return fail(PRF_EHIP, "fused scan kernel failed: %s", hipGetErrorString(e));
+            if (e != hipErrorNotReady) {
+                reset_vcounters(c);
+                return fail(PRF_EHIP, "fused scan kernel failed: %s", hipGetErrorString(e));
+            }
+            if (!timing) {
+                t0 = std::chrono::steady_clock::now();
+                timing = true;
+            } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                // the device-side blocks are not touched: the kernel may still be running
+                return fail(PRF_EHIP, "fused scan %llu did not post its counters within %.0f s (PRF_SCAN_TIMEOUT_S)",
+                            (unsigned long long)seq, limit_s);
+            }
         }
     }
 }
@@ -444,7 +477,13 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             // the counters to the host through mapped memory and clears the counter block of the next scan
             hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
             HIPCHK(hipEventRecord(ev_a, c->stream));
-            HIPCHK(prf_vertical_launch(c->stream, a, c->n_cus));
+            {
+                const hipError_t le = prf_vertical_launch(c->stream, a, c->n_cus);
+                if (le != hipSuccess) {
+                    reset_vcounters(c);
+                    return fail(PRF_EHIP, "fused scan launch failed: %s", hipGetErrorString(le));
+                }
+            }
             HIPCHK(hipEventRecord(ev_b, c->stream));
             // The scan is over for the host when the last workgroup has posted the counter block and this scan's
             // serial number in mapped host memory: poll that word instead of waiting for the stream to drain
@@ -645,7 +684,13 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
     a.dbg = nullptr;
     hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
     HIPCHK(hipEventRecord(ev_a, c->stream));
-    HIPCHK(prf_vertical_launch(c->stream, a, c->n_cus));
+    {
+        const hipError_t le = prf_vertical_launch(c->stream, a, c->n_cus);
+        if (le != hipSuccess) {
+            reset_vcounters(c);
+            return fail(PRF_EHIP, "fused scan launch failed: %s", hipGetErrorString(le));
+        }
+    }
     HIPCHK(hipEventRecord(ev_b, c->stream));
     sl.seq = a.seq;
     sl.positions = g->positions;

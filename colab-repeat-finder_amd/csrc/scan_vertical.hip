@@ -685,14 +685,24 @@ __global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vsca
             });
             u64 lt = 0;
             if (tid < NLT) lt = g.L[w0 + (NLF * NTH + tid) - LW];
-            uint4 ev = make_uint4(0, 0, 0, 0), en = ev;
-            const int n_extra = np * RG * extra;  // virtual-lane slots: (plane, row group, first lanes again)
-            if (tid < n_extra) {
-                const int p = tid / (RG * extra), erg = (tid / extra) % RG, el = tid % extra;
-                const uint4 *src = p == 0 ? ph : (p == 1 ? pL : px);
-                ev = src[(tile * RG + erg) * 64 + el];
-                en = src[((tile + 1) * RG + erg) * 64 + el];
-            }
+            // virtual-lane slots: (plane, row group, first lanes again).  3 planes x 8 row groups x 16 extra lanes (NC = 80,
+            // tile with N in reach) are 384 slots: two rounds of the 256 threads cover every instantiated width.
+            constexpr int NXR = (3 * RG * (NC - 64) + NTH - 1) / NTH;  // 1 for NC = 66, 72; 2 for NC = 80
+            static_assert(3 * RG * (NC - 64) <= NXR * NTH, "virtual-lane staging rounds do not cover the image width");
+            uint4 ev[NXR], en[NXR];
+            const int n_extra = np * RG * extra;
+            static_for<0, NXR>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int s = tid + r * NTH;
+                ev[r] = make_uint4(0, 0, 0, 0);
+                en[r] = ev[r];
+                if (s < n_extra) {
+                    const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
+                    const uint4 *src = p == 0 ? ph : (p == 1 ? pL : px);
+                    ev[r] = src[(tile * RG + erg) * 64 + el];
+                    en[r] = src[((tile + 1) * RG + erg) * 64 + el];
+                }
+            });
             vimg[(0 * RG + rg) * nc + l] = vh0;
             vimg[(0 * RG + rg + 4) * nc + l] = vh1;
             vimg[(1 * RG + rg) * nc + l] = vl0;
@@ -708,15 +718,19 @@ __global__ __launch_bounds__(64 * MAX_WAVES, OCC) void prf_vscan_kernel(prf_vsca
                 });
                 if (tid < NLT) lin[NLF * NTH + tid] = lt;
             }
-            if (tid < n_extra) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
-                const int p = tid / (RG * extra), erg = (tid / extra) % RG, el = tid % extra;
-                uint4 r;
-                r.x = (ev.x >> 1) | (en.x << 31);
-                r.y = (ev.y >> 1) | (en.y << 31);
-                r.z = (ev.z >> 1) | (en.z << 31);
-                r.w = (ev.w >> 1) | (en.w << 31);
-                vimg[(p * RG + erg) * nc + 64 + el] = r;
-            }
+            static_for<0, NXR>([&](auto rc) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
+                constexpr int r = decltype(rc)::value;
+                const int s = tid + r * NTH;
+                if (s < n_extra) {
+                    const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
+                    uint4 v;
+                    v.x = (ev[r].x >> 1) | (en[r].x << 31);
+                    v.y = (ev[r].y >> 1) | (en[r].y << 31);
+                    v.z = (ev[r].z >> 1) | (en[r].z << 31);
+                    v.w = (ev[r].w >> 1) | (en[r].w << 31);
+                    vimg[(p * RG + erg) * nc + 64 + el] = v;
+                }
+            });
         } else {
             for (int idx = tid; idx < np * RG * 64; idx += nt) {
                 const int p = idx / (RG * 64), rg = (idx / 64) % RG, l = idx % 64;

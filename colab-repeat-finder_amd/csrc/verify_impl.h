@@ -1,5 +1,5 @@
 // verify_impl.h -- candidate -> row logic shared by the flat phase-2 kernel (verify.hip) and the fused
-// tail of the bit-sliced kernel (scan_vertical_impl.h).
+// tail of the bit-sliced kernel (scan_vertical.hip).
 //
 // What it replaces: PerfectRepeatTracker.output_interval_if_it_passes_filters()
 // (reference utils/perfect_repeat_tracker.py:71-101) and consists_of_perfect_repeats() (:108-142),

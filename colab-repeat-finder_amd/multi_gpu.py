@@ -59,17 +59,42 @@ def gather_rows(local_rows, dist, torch, device):
     return rows[order]
 
 
+class ShardError(RuntimeError):
+    """A rank's scan failed; raised on EVERY rank with the failing rank's message, before any row collective."""
+
+    def __init__(self, rank, kind, message):
+        super().__init__(f"rank {rank}: {kind}: {message}")
+        self.rank, self.kind, self.message = rank, kind, message
+
+
+def agree_or_raise(error, dist, torch, device):
+    """Collective: every rank passes its local exception (or None).  If any rank failed, every rank raises the
+    ShardError of the lowest failing rank -- nobody is left waiting in the row gather for a peer that has died."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) == 0:
+        return
+    msgs = [None] * world
+    dist.all_gather_object(msgs, None if error is None else (type(error).__name__, str(getattr(error, "message", error))))
+    bad = next(i for i, m in enumerate(msgs) if m is not None)
+    raise ShardError(bad, msgs[bad][0], msgs[bad][1])
+
+
 def scan_contigs_sharded(contigs, settings, scan_fn, dist, torch, device):
     """contigs: list of bytes, identical on every rank.  scan_fn(list_of_bytes, settings) -> rows with
     contig indices local to the list it was given.  Returns the rows of ALL contigs (global contig indices,
-    sorted) on rank 0, None elsewhere."""
+    sorted) on rank 0, None elsewhere.  A failure of scan_fn on one rank is raised on all of them (ShardError)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = plan_contig_shards([len(c) for c in contigs], world)[rank]
-    if mine:
-        rows = np.array(scan_fn([contigs[i] for i in mine], settings), dtype=ROW_DTYPE)
-        if len(rows):
-            rows = rows.copy()
-            rows["contig"] = np.asarray(mine, dtype=np.uint32)[rows["contig"]]
-    else:
-        rows = np.zeros(0, dtype=ROW_DTYPE)
+    rows, error = np.zeros(0, dtype=ROW_DTYPE), None
+    try:
+        if mine:
+            rows = np.array(scan_fn([contigs[i] for i in mine], settings), dtype=ROW_DTYPE)
+            if len(rows):
+                rows = rows.copy()
+                rows["contig"] = np.asarray(mine, dtype=np.uint32)[rows["contig"]]
+    except Exception as exc:          # noqa: BLE001 -- whatever it is, the peers must hear about it
+        error = exc
+    agree_or_raise(error, dist, torch, device)
     return gather_rows(rows, dist, torch, device)

@@ -2,7 +2,12 @@
 
 synth_bases()      SURVEY 8(d) counter-based generator: base i = "ACGT"[splitmix64(seed + (i+1)*phi) >> 62];
                    reproducible in Python, C (oracle/prf_oracle.c: prf_oracle_synth) and on any device.
-chr_standin()      stand-in for a human chromosome: the same uniform background, N blocks where hg38 has
+standin2()         the stand-in recipe in a form that every position can compute for itself (integer arithmetic only), so
+                   that a whole hg38-shaped genome is generated ON the device (libprf: prf_genome_standin) and any
+                   window of it on the host: uniform background, N blocks at both ends and a centromere-like gap,
+                   one planted perfect tandem repeat per 588-position slot (1 700 / Mbp), motif sizes after the
+                   reference's golden chr22 BED, motif = the background at the repeat's own position.
+chr_standin()      (older recipe, kept for the pinned chr22 inputs) stand-in for a human chromosome: the same uniform background, N blocks where hg38 has
                    them (chr22: the first 10.51 Mb and the last 10 kb), and planted perfect tandem repeats at
                    ~1.7 k/Mbp whose motif sizes follow the reference's golden chr22 BED
                    (benchmark/repeat_finder/chr22_repeats.bed: 1:20000 2:12110 3:21917 4:9475 5:3207 6:929)
@@ -81,3 +86,77 @@ def chr_standin(length=CHR22_LEN, seed=22, n_head=10_510_000, n_tail=10_000, rep
     if n_tail:
         seq[length - n_tail:] = ord("N")
     return seq
+
+
+# ---- stand-in recipe 2: position-computable (numpy here, HIP in csrc/pack.hip::prf_standin2_kernel) ----------------
+SLOT2 = 588                      # positions per planted repeat: 1e6 / 588 = 1 700.7 repeats per Mbp
+_SLOT_SALT = np.uint64(0xD1B54A32D192ED03)
+# motif size 1..6: cumulative golden-BED histogram (20000, 12110, 21917, 9475, 3207, 929) scaled to 95 % of 2^16
+_K_CUM = np.array([18412, 29561, 49738, 58461, 61413, 62268], dtype=np.int64)
+# copies = 3 + geometric(ratio 0.67): v (24 bits) below floor(2^24 * 0.67^(i+1)) adds one copy, i = 0..15
+_COPY_TH = np.array([int((1 << 24) * 0.67 ** (i + 1)) for i in range(16)], dtype=np.int64)
+
+
+def standin2_layout(n):
+    """(n_head, n_tail, gap_lo, gap_hi): N blocks of a contig of length n (gap_lo == gap_hi: no inner gap)."""
+    n_head = n_tail = min(10_000, n // 100)
+    if n >= 1_000_000:
+        gap_lo = n // 8 * 3 + 12_345
+        return n_head, n_tail, gap_lo, gap_lo + n // 25
+    return n_head, n_tail, 0, 0
+
+
+def _slot_params(seed, slots):
+    """k, span, offset-in-slot of the planted repeat of every slot index in `slots` (int64 arrays)."""
+    with np.errstate(over="ignore"):
+        d = _splitmix((np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ _SLOT_SALT) + (slots.astype(np.uint64) + np.uint64(1)) * _PHI)
+        d2 = _splitmix(d + _PHI)
+    u = (d >> np.uint64(48)).astype(np.int64)
+    v = ((d >> np.uint64(24)) & np.uint64(0xFFFFFF)).astype(np.int64)
+    w = (d & np.uint64(0xFFFFFF)).astype(np.int64)
+    x = (d2 >> np.uint64(32)).astype(np.int64)
+    k = np.searchsorted(_K_CUM, u, side="right") + 1
+    t = u - int(_K_CUM[-1])
+    k = np.where(u >= _K_CUM[-1], 7 + (t * t * 44) // (3268 * 3268), k)
+    copies = 3 + (v[:, None] < _COPY_TH[None, :]).sum(axis=1)
+    span = np.maximum(np.minimum(k * copies + w % k, 500), 10)
+    off = x % (SLOT2 - span)
+    return k, span, off
+
+
+def standin2(n, seed, start=0, count=None):
+    """ASCII uint8 array: positions [start, start+count) of the recipe-2 stand-in contig (n, seed)."""
+    count = n - start if count is None else count
+    assert 0 <= start and start + count <= n
+    seq = synth_bases(count, seed, start)
+    n_head, n_tail, gap_lo, gap_hi = standin2_layout(n)
+    body_lo, body_hi = n_head, n - n_tail
+    n_slots = (body_hi - body_lo) // SLOT2
+    if n_slots > 0 and count > 0:
+        s0 = max(0, (start - body_lo) // SLOT2)
+        s1 = min(n_slots, (start + count - 1 - body_lo) // SLOT2 + 1)
+        if s1 > s0:
+            slots = np.arange(s0, s1, dtype=np.int64)
+            k, span, off = _slot_params(seed, slots)
+            p = body_lo + slots * SLOT2 + off
+            tot = int(span.sum())
+            rep = np.repeat(np.arange(len(slots)), span)
+            j = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(span) - span, span)     # 0 .. span-1 per repeat
+            dst = p[rep] + j
+            src = p[rep] + j % k[rep]
+            keep = (dst >= start) & (dst < start + count)
+            dst, src = dst[keep], src[keep]
+            seq[dst - start] = _ACGT[synth_codes_at(src, seed)]
+    lo, hi = start, start + count
+    for a, b in ((0, n_head), (n - n_tail, n), (gap_lo, gap_hi)):
+        a, b = max(a, lo), min(b, hi)
+        if b > a:
+            seq[a - lo:b - lo] = ord("N")
+    return seq
+
+
+def synth_codes_at(idx, seed):
+    """2-bit draws of the background generator at arbitrary positions (int64 array)."""
+    with np.errstate(over="ignore"):
+        z = _splitmix(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (idx.astype(np.uint64) + np.uint64(1)) * _PHI)
+    return (z >> np.uint64(62)).astype(np.uint8)

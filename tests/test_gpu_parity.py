@@ -51,12 +51,23 @@ def test_reference_unit_vectors(detect, golden_unit):
 
 def test_fuzz_small(detect, golden_fuzz):
     n = 0
+    refused = 0
     for case in golden_fuzz:
         if case["settings"]["min_repeats"] < 2:
+            # outside the closed form: the product refuses loudly, it never guesses
+            from helpers import settings_ns
+            try:
+                detect(case["seq"], settings_ns(case["settings"]))
+            except NotImplementedError:
+                refused += 1
+            except (ValueError, IndexError, AssertionError) as exc:   # raised in front of the scan, as the reference does
+                assert type(exc).__name__ == expected(case)[0], case
+            else:
+                raise AssertionError(f"min_repeats == 1 was served: {case}")
             continue
         n += 1
         assert outcome(detect, case["seq"], case["settings"]) == expected(case), case
-    assert n > 3000
+    assert n > 3000 and refused > 300
 
 
 def test_adversarial(detect, golden_adversarial):
@@ -133,6 +144,39 @@ def test_fused_bit_sliced_kernel_param_sweep_vs_oracle_and_generic(ctx):
             rows2, stats2 = g.scan(kmin, kmax, r, span, flags=prf_native.SCAN_FORCE_GENERIC)
             assert stats2.path == 0
             assert rows_as_tuples(rows2) == rows_as_tuples(rows)
+    finally:
+        g.free()
+
+
+def test_widest_lds_image_with_n_blocks_kmax_260_to_480(ctx):
+    """Motif sizes above ~260 take the widest LDS image of the fused kernel (80 virtual lanes: 16 extra lanes x 8 row
+    groups x 3 planes = 384 staged slots on a tile with N in reach, more than one round of the 256 threads).  N blocks
+    inside tiles, at tile edges and at the contig's end, long-period repeats next to them: fused == oracle == generic."""
+    import prf_native
+    import synth
+    n = 330_000
+    seq = bytearray(synth.chr_standin(length=n, seed=41, n_head=9_000, n_tail=700, repeats_per_mbp=3000).tobytes())
+    rng = np.random.default_rng(41)
+    for p, ln in ((65_536 - 3, 9), (100_000, 1), (131_072 + 2_000, 300), (200_000, 5_000), (262_144 - 1_000, 1_001)):
+        seq[p:p + ln] = b"N" * ln
+    for p, k, copies in ((20_000, 261, 3.2), (64_000, 300, 4), (99_000, 333, 3), (130_500, 470, 3.1), (150_000, 480, 5),
+                         (196_000, 279, 3.5), (258_000, 400, 3), (n - 3_000, 264, 3.3), (40_000, 128, 9), (300_000, 97, 4)):
+        motif = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+        body = (motif * (int(copies) + 2))[:int(k * copies)]
+        seq[p:p + len(body)] = body
+    seq = bytes(seq)
+    assert b"N" * 300 in seq
+    g = ctx.load([seq], 480)
+    try:
+        for kmin, kmax, r, span in ((1, 260, 3, 9), (250, 300, 3, 9), (1, 480, 3, 9), (257, 480, 2, 700), (470, 480, 4, 1)):
+            assert prf_native.plan_describe(kmin, kmax, r, span)["nc"] == 80
+            rows, stats = g.scan(kmin, kmax, r, span)
+            assert stats.path == 1, (kmin, kmax, r, span)
+            got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+            assert got == oracle_rows(seq, kmin, kmax, r, span), (kmin, kmax, r, span)
+            rows2, stats2 = g.scan(kmin, kmax, r, span, flags=prf_native.SCAN_FORCE_GENERIC)
+            assert stats2.path == 0 and rows_as_tuples(rows2) == rows_as_tuples(rows)
+        assert max(k for _s, _e, k in got) >= 470
     finally:
         g.free()
 
