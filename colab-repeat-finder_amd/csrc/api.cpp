@@ -67,7 +67,6 @@ struct prf_ctx {
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
-    int n_cus = 256;
     u32 parity = 0;
     u64 scan_seq = 0;
     // generic path scratch
@@ -91,10 +90,12 @@ struct prf_ctx {
     u64 *h_async = nullptr;         // slot 1's counter block
     prf_hit_dev *d_hits_async = nullptr;
     u64 hit_cap_async = 0;
-    // fused (bit-sliced) path scratch: one row slab per tile
-    prf_hit_dev *d_hit_slabs = nullptr;
-    u64 slab_tiles = 0;
+    // fused (bit-sliced) path scratch: one row slab and one row count per launch slot (= scanned tile)
+    prf_hit_dev *d_slabs = nullptr;
+    u32 *d_slab_count = nullptr;
+    u64 slab_slots = 0;
     u32 slab_cap = 0;
+    bool last_sorted = true;        // the rows of the last scan left the device sorted by (contig, start, end)
     // where the rows of the last scan are
     u64 last_nhits = 0;
 };
@@ -110,7 +111,24 @@ struct prf_genome {
     u64 *H = nullptr, *L = nullptr, *X = nullptr;  // point PRF_FRONT_PAD words into their allocations
     u64 *d_base = nullptr;
     prf_vplanes vp;      // bit-sliced copy for scan_vertical
+    // active selection (prf_genome_select): the scans of this genome cover only these tiles.  Off: the whole genome.
+    bool sel_on = false;
+    u32 *d_sel_list = nullptr;
+    u32 sel_n = 0, sel_flat = ~0u;
+    u64 sel_positions = 0;
+    std::vector<std::pair<u64, u64>> sel_tiles;  // merged [first, last) tile ranges, ascending
 };
+
+// what a scan of the genome launches
+struct launch_view {
+    const u32 *list;
+    u32 n, flat;
+    u64 positions;
+};
+static launch_view active_launch(const prf_genome *g) {
+    if (g->sel_on) return launch_view{g->d_sel_list, g->sel_n, g->sel_flat, g->sel_positions};
+    return launch_view{g->vp.launch_list, g->vp.n_launch, g->vp.flat_base, g->positions};
+}
 
 extern "C" {
 
@@ -142,7 +160,6 @@ int prf_open(int device_id, prf_ctx **out) {
     prf_ctx *c = new (std::nothrow) prf_ctx();
     if (!c) return fail(PRF_ENOMEM, "prf_open: out of host memory");
     c->dev = device_id;
-    if (prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     struct guard_t {  // a failure below must not leak the half-built context
         prf_ctx *c;
         ~guard_t() { if (c) prf_close(c); }
@@ -174,7 +191,8 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_vcounters);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
-    (void)hipFree(c->d_hit_slabs);
+    (void)hipFree(c->d_slabs);
+    (void)hipFree(c->d_slab_count);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ring)
@@ -194,15 +212,17 @@ void prf_genome_free(prf_genome *g) {
     (void)hipFree(g->vp.VL);
     (void)hipFree(g->vp.VX);
     (void)hipFree(g->vp.tile_class);
-    (void)hipFree(g->vp.tile_list);
+    (void)hipFree(g->vp.launch_list);
+    (void)hipFree(g->d_sel_list);
     delete g;
 }
 
 uint64_t prf_genome_positions(const prf_genome *g) { return g ? g->positions : 0; }
 
 // contigs[i].ascii == nullptr with seeds != nullptr: contig i is generated on the device from seeds[i]
+// recipe (with seeds): 1 = uniform background, 2 = stand-in recipe 2 (N blocks + planted repeats)
 static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmax_hint, prf_genome **out,
-                            const uint64_t *seeds = nullptr) {
+                            const uint64_t *seeds = nullptr, int recipe = 1) {
     if (!c || !out || n_contigs < 0 || (n_contigs > 0 && !contigs))
         return fail(PRF_EINVAL, "prf_genome_load: bad arguments");
     *out = nullptr;
@@ -228,7 +248,7 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     }
     if (cur == 0) cur = PRF_TILE;
     g->G = cur + PRF_TILE;  // one all-gap sentinel tile: every walk to the right ends inside the arrays
-    if (g->G >= (1ull << PRF_CAND_POS_BITS)) return fail(PRF_EUNSUPPORTED, "prf_genome_load: input too large");
+    if (g->G >= (1ull << 40)) return fail(PRF_EUNSUPPORTED, "prf_genome_load: input too large (2^40 positions)");  // row keys: 40-bit offsets
     g->nwords = g->G / 64;
     g->padw = kmax_hint / 64 + 8;
 
@@ -241,7 +261,9 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     HIPCHK(prf_launch_fill_u64(c->stream, (u64 *)asc, g->G / 8, 0x4E4E4E4E4E4E4E4Eull));  // 'N' everywhere
     for (int i = 0; i < n_contigs; i++) {
         if (!contigs[i].len) continue;
-        if (seeds)  // the generator writes whole 16-byte groups; the tail beyond len is 'N' again, like the gap
+        if (seeds && recipe == 2)
+            HIPCHK(prf_launch_standin2(c->stream, asc + g->base[i], contigs[i].len, seeds[i]));
+        else if (seeds)  // the generator writes whole 16-byte groups; the tail beyond len is 'N' again, like the gap
             HIPCHK(prf_launch_synth(c->stream, asc + g->base[i], contigs[i].len, seeds[i]));
         else
             HIPCHK(hipMemcpyAsync(asc + g->base[i], contigs[i].ascii, contigs[i].len, hipMemcpyHostToDevice, c->stream));
@@ -308,6 +330,19 @@ int prf_genome_synth(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, in
         return fail(PRF_ENOMEM, "prf_genome_synth: out of host memory");
     } catch (...) {
         return fail(PRF_EHIP, "prf_genome_synth: unexpected exception");
+    }
+}
+
+int prf_genome_standin(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, int n_contigs, uint32_t kmax_hint, prf_genome **out) {
+    if (n_contigs < 0 || (n_contigs > 0 && (!lens || !seeds))) return fail(PRF_EINVAL, "prf_genome_standin: bad arguments");
+    try {
+        std::vector<prf_contig> cs((size_t)(n_contigs > 0 ? n_contigs : 1));
+        for (int i = 0; i < n_contigs; i++) cs[i] = prf_contig{nullptr, lens[i]};
+        return genome_load_impl(c, cs.data(), n_contigs, kmax_hint, out, seeds, 2);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_genome_standin: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_genome_standin: unexpected exception");
     }
 }
 
@@ -389,16 +424,56 @@ static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
     return PRF_OK;
 }
 
-static int ensure_slabs(prf_ctx *c, u64 ntiles, u32 cap) {
-    if (ntiles > c->slab_tiles || cap > c->slab_cap) {
-        (void)hipFree(c->d_hit_slabs);
-        c->d_hit_slabs = nullptr;
-        c->slab_tiles = 0;
+static int ensure_slabs(prf_ctx *c, u64 nslots, u32 cap) {
+    if (nslots > c->slab_slots || cap > c->slab_cap) {
+        nslots = std::max<u64>(nslots, c->slab_slots);
+        cap = std::max<u32>(cap, c->slab_cap);
+        (void)hipFree(c->d_slabs);
+        (void)hipFree(c->d_slab_count);
+        c->d_slabs = nullptr;
+        c->d_slab_count = nullptr;
+        c->slab_slots = 0;
         c->slab_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->d_hit_slabs, ntiles * (u64)cap * sizeof(prf_hit_dev)));
-        c->slab_tiles = ntiles;
+        HIPCHK(hipMalloc((void **)&c->d_slabs, nslots * (u64)cap * sizeof(prf_hit_dev)));
+        HIPCHK(hipMalloc((void **)&c->d_slab_count, nslots * sizeof(u32)));
+        c->slab_slots = nslots;
         c->slab_cap = cap;
     }
+    return PRF_OK;
+}
+
+// The two launches of a fused scan: tiles -> sorted slabs, slabs -> one compact sorted array + counters to the host.
+// HIP events bracket the pair.
+static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, u32 min_repeats, u32 min_span, prf_hit_dev *rows,
+                        u64 rows_cap, u32 count_row, u64 *host_counters_dev, u64 *seq_out) {
+    const launch_view lv = active_launch(g);
+    prf_vscan_args a;
+    a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
+    a.H = g->H; a.L = g->L; a.X = g->X;
+    a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
+    a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.slab_cap = c->slab_cap;
+    a.min_repeats = min_repeats; a.min_span = min_span;
+    a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
+    a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
+    a.plan = plan;
+    prf_vgather_args ga;
+    ga.slabs = c->d_slabs; ga.slab_count = c->d_slab_count; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
+    ga.rows = rows; ga.rows_cap = rows_cap; ga.count_row = count_row;
+    ga.counters = a.counters;
+    ga.host_counters = host_counters_dev;
+    ga.seq = ++c->scan_seq;
+    ga.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
+    c->parity ^= 1u;
+    hipEvent_t ev_a = c->ring[2 * (ga.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (ga.seq % PRF_TIMING_RING) + 1];
+    HIPCHK(hipEventRecord(ev_a, c->stream));
+    hipError_t le = prf_vertical_launch(c->stream, a);
+    if (le == hipSuccess) le = prf_vertical_gather(c->stream, ga);
+    if (le != hipSuccess) {
+        reset_vcounters(c);
+        return fail(PRF_EHIP, "fused scan launch failed: %s", hipGetErrorString(le));
+    }
+    HIPCHK(hipEventRecord(ev_b, c->stream));
+    *seq_out = ga.seq;
     return PRF_OK;
 }
 
@@ -421,75 +496,45 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     HIPCHK(hipSetDevice(c->dev));
 
     prf_planes pl{g->H, g->L, g->X};
-    prf_vscan_args va;
-    bool vs = !(flags & PRF_SCAN_FORCE_GENERIC) && prf_vertical_plan(kmin, kmax, min_repeats, min_span, &va.plan);
-    const u64 ntiles = g->G / PRF_TILE - 1;  // the sentinel tile is never scanned
-    u64 want_cand = std::max<u64>(c->cand_cap, g->positions / 8 + 65536);
-    u64 want_hits = std::max<u64>(c->hit_cap, g->positions / 32 + 65536);
-    u32 slab_cap = std::max<u32>(c->slab_cap, 512u);
+    prf_vplan plan;
+    bool vs = !(flags & PRF_SCAN_FORCE_GENERIC) && prf_vertical_plan(kmin, kmax, min_repeats, min_span, &plan);
+    const launch_view lv = active_launch(g);
+    u64 want_cand = std::max<u64>(c->cand_cap, lv.positions / 8 + 65536);
+    u64 want_hits = std::max<u64>(c->hit_cap, lv.positions / 32 + 65536);
+    u32 slab_cap = std::max<u32>(c->slab_cap, 320u);
     float ms01 = 0, ms12 = 0;
     u64 ncand = 0, nhits = 0;
     u32 launches = 0;
+    bool sorted_on_device = false;
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) return fail(PRF_EHIP, "prf_scan_genome: buffers still overflowing after 8 attempts");
         bool again = false;
         if (vs) {
-            // ---- fused bit-sliced kernel: scan + verify + rows in one launch ----
-            const u64 nslabs = ntiles * 4;  // a tile with N in reach is scanned by 4 workgroups, each with its own slab
-            int rc = ensure_slabs(c, nslabs, slab_cap);
-            if (rc) return rc;
-            prf_vscan_args &a = va;
-            a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
-            a.H = g->H; a.L = g->L; a.X = g->X;
-            a.tile_list = g->vp.tile_list;
-            a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
-            a.clean_base = g->vp.clean_base;
-            a.hit_slabs = c->d_hit_slabs; a.hit_cap = c->slab_cap;
-            a.min_repeats = min_repeats; a.min_span = min_span;
-            a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
-            if (a.n_clean + a.n_mixed == 0) {  // nothing but N (or no contig at all): no tile to launch, no rows
+            // ---- fused bit-sliced kernel (scan + verify + sorted rows per tile), then the row gather ----
+            if (lv.n == 0) {  // nothing but N (or no contig at all): no tile to launch, no rows
                 nhits = ncand = 0;
                 launches = 0;
+                sorted_on_device = true;
                 if (c->sink) {
                     HIPCHK(hipMemsetAsync(c->sink + c->sink_cap, 0, sizeof(prf_hit_dev), c->stream));
                     HIPCHK(hipStreamSynchronize(c->stream));
                 }
                 break;
             }
-            a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
-            a.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
-            a.host_counters = c->h_counters_dev;
-            a.seq = ++c->scan_seq;
-            c->parity ^= 1u;
-            a.dbg = nullptr;
-#ifdef PRF_STAMPS
-            static u64 *dbg_buf = nullptr;
-            if (!dbg_buf) HIPCHK(hipMalloc((void **)&dbg_buf, (size_t)(1 << 20) * 32 * sizeof(u64)));
-            HIPCHK(hipMemsetAsync(dbg_buf, 0, (size_t)(1 << 20) * 32 * sizeof(u64), c->stream));
-            a.dbg = dbg_buf;
-#endif
+            int rc = ensure_slabs(c, lv.n, slab_cap);
+            if (rc) return rc;
             rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
             if (rc) return rc;
-            a.rows = c->sink ? c->sink : c->d_hits;
-            a.rows_cap = c->sink ? c->sink_cap : c->hit_cap;
-            a.count_row = c->sink ? 1u : 0u;
-            // ONE kernel per scan: it also compacts the rows (a reservation per workgroup in the row array), hands
-            // the counters to the host through mapped memory and clears the counter block of the next scan
-            hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
-            HIPCHK(hipEventRecord(ev_a, c->stream));
-            {
-                const hipError_t le = prf_vertical_launch(c->stream, a, c->n_cus);
-                if (le != hipSuccess) {
-                    reset_vcounters(c);
-                    return fail(PRF_EHIP, "fused scan launch failed: %s", hipGetErrorString(le));
-                }
-            }
-            HIPCHK(hipEventRecord(ev_b, c->stream));
-            // The scan is over for the host when the last workgroup has posted the counter block and this scan's
-            // serial number in mapped host memory: poll that word instead of waiting for the stream to drain
-            // (the kernel's end-of-grid handshake, the event and the wake-up cost ~5 us of a ~50 us chr22 scan).
-            // Everything that consumes the rows is enqueued on the same stream, hence ordered after the kernel.
-            rc = wait_for_seq(c, a.seq);
+            u64 seq = 0;
+            rc = launch_fused(c, g, plan, min_repeats, min_span, c->sink ? c->sink : c->d_hits, c->sink ? c->sink_cap : c->hit_cap,
+                              c->sink ? 1u : 0u, c->h_counters_dev, &seq);
+            if (rc) return rc;
+            hipEvent_t ev_a = c->ring[2 * (seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (seq % PRF_TIMING_RING) + 1];
+            // The scan is over for the host when the gather's last workgroup has posted the counter block and this
+            // scan's serial number in mapped host memory: poll that word instead of waiting for the stream to drain
+            // (the kernel's end-of-grid handshake, the event and the wake-up cost ~5 us).
+            // Everything that consumes the rows is enqueued on the same stream, hence ordered after the kernels.
+            rc = wait_for_seq(c, seq);
             if (rc) return rc;
             // a row sink is read by the caller on streams of its own: wait until every workgroup has copied its rows
             if (c->sink) HIPCHK(hipStreamSynchronize(c->stream));
@@ -498,35 +543,16 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 HIPCHK(hipEventElapsedTime(&ms01, ev_a, ev_b));
             }
             ms12 = 0;
-            launches = 1;
-            nhits = c->h_counters[PRF_CNT_ROWS] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+            launches = 2;
+            nhits = c->h_counters[PRF_CNT_ROWS];
+            sorted_on_device = c->h_counters[PRF_CNT_UNSORTED] == 0;
             ncand = 0;
             for (int sh = 0; sh < PRF_CNT_NSHARD; sh++)
                 ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
-#ifdef PRF_STAMPS
-            if (getenv("PRF_STAMPS_OUT")) {
-                fprintf(stderr, "[prf] plan: %u waves, %u tasks\n", a.plan.n_waves, a.plan.n_tasks);
-                for (u32 w = 0; w < a.plan.n_waves; w++)
-                    for (u32 ti = a.plan.wave_begin[w]; ti < a.plan.wave_begin[w + 1]; ti++)
-                        fprintf(stderr, "[prf]   wave %u slot %u: kind %u k0 %u valid %02x stride %u\n", w, ti - a.plan.wave_begin[w],
-                                a.plan.tasks[ti].kind, a.plan.tasks[ti].k0, a.plan.tasks[ti].valid, a.plan.tasks[ti].stride);
-            }
-            if (const char *path = getenv("PRF_STAMPS_OUT")) {
-                const size_t nu = (size_t)(a.n_clean + 4 * a.n_mixed) * 4 * 16;
-                std::vector<u64> host(nu);
-                HIPCHK(hipMemcpy(host.data(), a.dbg, nu * sizeof(u64), hipMemcpyDeviceToHost));
-                if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, nu, f); fclose(f); }
-                // per-record verify costs of the cooperative pass: [block][idx < 1024]{cycles, info}
-                const size_t nv = (size_t)(a.n_clean + 4 * a.n_mixed) * 1024 * 2;
-                std::vector<u64> hv(nv);
-                HIPCHK(hipMemcpy(hv.data(), a.dbg + (1ull << 24), nv * sizeof(u64), hipMemcpyDeviceToHost));
-                std::string p2 = std::string(path) + ".verify";
-                if (FILE *f = fopen(p2.c_str(), "wb")) { fwrite(hv.data(), 8, nv, f); fclose(f); }
-            }
-#endif
             if (getenv("PRF_DEBUG"))
-                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu hit_ovf %llu ms %.4f\n", (unsigned long long)nhits,
-                        (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], ms01);
+                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu hit_ovf %llu unsorted %llu ms %.4f\n", (unsigned long long)nhits,
+                        (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF],
+                        (unsigned long long)c->h_counters[PRF_CNT_UNSORTED], ms01);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
             if (!again && c->sink && nhits > c->sink_cap)
@@ -542,8 +568,15 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             if (rc) return rc;
             HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
-            HIPCHK(prf_launch_scan_generic(c->stream, pl, 0, g->nwords - PRF_TILE_WORDS, kmin, kmax, min_repeats, min_span,
-                                           c->d_cand, c->cand_cap, c->d_counters));
+            // a run belongs to the word that holds its first position: disjoint word ranges give disjoint row sets
+            if (g->sel_on) {
+                for (const auto &tr : g->sel_tiles)
+                    HIPCHK(prf_launch_scan_generic(c->stream, pl, tr.first * PRF_TILE_WORDS, tr.second * PRF_TILE_WORDS, kmin, kmax,
+                                                   min_repeats, min_span, c->d_cand, c->cand_cap, c->d_counters));
+            } else {
+                HIPCHK(prf_launch_scan_generic(c->stream, pl, 0, g->nwords - PRF_TILE_WORDS, kmin, kmax, min_repeats, min_span,
+                                               c->d_cand, c->cand_cap, c->d_counters));
+            }
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
             HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base,
                                      (u32)g->base.size(), c->d_hits, c->hit_cap, c->d_counters));
@@ -572,17 +605,19 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     }
     c->last_nhits = nhits;
     c->last_rows = c->sink ? c->sink : c->d_hits;
+    c->last_sorted = sorted_on_device;
     if (stats) {
         stats->phase1_ms = ms01;
         stats->phase2_ms = ms12;
         stats->scan_ms = (double)ms01 + (double)ms12;
-        stats->positions = g->positions;
-        stats->packed_bytes = (g->positions + 3) / 4;
+        stats->positions = lv.positions;
+        stats->packed_bytes = (lv.positions + 3) / 4;
         stats->n_candidates = ncand;
         stats->n_hits = nhits;
         stats->n_launches = launches;
         stats->path = vs ? 1 : 0;
-        stats->seq = vs ? c->scan_seq : 0;
+        stats->seq = vs && launches ? c->scan_seq : 0;
+        stats->sorted_on_device = sorted_on_device ? 1u : 0u;
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
     if (nhits == 0) return PRF_OK;
@@ -597,12 +632,15 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         free(rows);
         return fail(PRF_EHIP, "row copy failed: %s", hipGetErrorString(e));
     }
-    std::sort(rows, rows + nhits, [](const prf_hit &a, const prf_hit &b) {
-        if (a.contig != b.contig) return a.contig < b.contig;
-        if (a.start != b.start) return a.start < b.start;
-        if (a.end != b.end) return a.end < b.end;
-        return a.k < b.k;
-    });
+    // The fused path hands the rows over sorted by (contig, start, end) (reference perfect_repeat_finder.py:81).  The
+    // generic path, and a fused scan in which some tile held more rows than its LDS sort list, are sorted here.
+    if (!sorted_on_device)
+        std::sort(rows, rows + nhits, [](const prf_hit &a, const prf_hit &b) {
+            if (a.contig != b.contig) return a.contig < b.contig;
+            if (a.start != b.start) return a.start < b.start;
+            if (a.end != b.end) return a.end < b.end;
+            return a.k < b.k;
+        });
     out->rows = rows;
     out->n = nhits;
     return PRF_OK;
@@ -640,12 +678,12 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
     if (c->sink) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: not with a row sink");
     if (kmin < 1 || kmax < kmin || min_repeats < 2 || min_span < 1 || kmax > g->kmax_hint)
         return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: parameters the synchronous call would refuse or serve otherwise");
-    prf_vscan_args a;
-    if (!prf_vertical_plan(kmin, kmax, min_repeats, min_span, &a.plan))
+    prf_vplan plan;
+    if (!prf_vertical_plan(kmin, kmax, min_repeats, min_span, &plan))
         return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: no fused plan for these parameters");
-    if (g->vp.n_clean + g->vp.n_mixed == 0) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: nothing to launch");
-    const u64 nslabs = (g->G / PRF_TILE - 1) * 4;
-    if (nslabs > c->slab_tiles || c->slab_cap == 0 || c->hit_cap == 0)
+    const launch_view lv = active_launch(g);
+    if (lv.n == 0) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: nothing to launch");
+    if (lv.n > c->slab_slots || c->slab_cap == 0 || c->hit_cap == 0)
         return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: scan this genome synchronously once first (buffers are sized there)");
     HIPCHK(hipSetDevice(c->dev));
     prf_ctx::async_slot &sl = c->slot[c->async_n & 1u];
@@ -667,35 +705,17 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
         sl.h = c->h_async; sl.rows = c->d_hits_async;
         if (!sl.h_dev) HIPCHK(hipHostGetDevicePointer((void **)&sl.h_dev, c->h_async, 0));
     }
-    a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
-    a.H = g->H; a.L = g->L; a.X = g->X;
-    a.tile_list = g->vp.tile_list;
-    a.n_clean = g->vp.n_clean; a.n_mixed = g->vp.n_mixed;
-    a.clean_base = g->vp.clean_base;
-    a.hit_slabs = c->d_hit_slabs; a.hit_cap = c->slab_cap;
-    a.rows = sl.rows; a.rows_cap = c->hit_cap; a.count_row = 0;
-    a.min_repeats = min_repeats; a.min_span = min_span;
-    a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
-    a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
-    a.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
-    a.host_counters = sl.h_dev;
-    a.seq = ++c->scan_seq;
-    c->parity ^= 1u;
-    a.dbg = nullptr;
-    hipEvent_t ev_a = c->ring[2 * (a.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (a.seq % PRF_TIMING_RING) + 1];
-    HIPCHK(hipEventRecord(ev_a, c->stream));
+    // (the slabs are shared by the two scans in flight: kernels of one stream run in order, and a scan's gather has read
+    // the slabs before the next scan's tiles write them)
+    u64 seq = 0;
     {
-        const hipError_t le = prf_vertical_launch(c->stream, a, c->n_cus);
-        if (le != hipSuccess) {
-            reset_vcounters(c);
-            return fail(PRF_EHIP, "fused scan launch failed: %s", hipGetErrorString(le));
-        }
+        const int rc = launch_fused(c, g, plan, min_repeats, min_span, sl.rows, c->hit_cap, 0u, sl.h_dev, &seq);
+        if (rc) return rc;
     }
-    HIPCHK(hipEventRecord(ev_b, c->stream));
-    sl.seq = a.seq;
-    sl.positions = g->positions;
+    sl.seq = seq;
+    sl.positions = lv.positions;
     c->async_n++;
-    *seq_out = a.seq;
+    *seq_out = seq;
     return PRF_OK;
 }
 
@@ -715,20 +735,22 @@ int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
     int rc = wait_for_seq(c, seq, sl->h);
     sl->seq = 0;
     if (rc) return rc;
-    const u64 nhits = sl->h[PRF_CNT_ROWS] & ((1ull << PRF_ROWS_TICKET_SHIFT) - 1ull);
+    const u64 nhits = sl->h[PRF_CNT_ROWS];
     u64 ncand = 0;
     for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) ncand += sl->h[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
     if (sl->h[PRF_CNT_HIT_OVF] > c->slab_cap || nhits > c->hit_cap)
         return fail(PRF_EUNSUPPORTED, "prf_scan_wait: the buffers sized by the last synchronous scan overflowed; scan synchronously");
     c->last_nhits = nhits;
     c->last_rows = sl->rows;
+    c->last_sorted = sl->h[PRF_CNT_UNSORTED] == 0;
     if (stats) {
         memset(stats, 0, sizeof *stats);
+        stats->sorted_on_device = c->last_sorted ? 1u : 0u;
         stats->positions = sl->positions;
         stats->packed_bytes = (sl->positions + 3) / 4;
         stats->n_candidates = ncand;
         stats->n_hits = nhits;
-        stats->n_launches = 1;
+        stats->n_launches = 2;
         stats->path = 1;
         stats->seq = seq;
     }
@@ -756,6 +778,77 @@ int prf_last_hits_to_device(prf_ctx *c, void *dst, uint64_t capacity_rows, int c
     }
     if (n || count_row) HIPCHK(hipStreamSynchronize(c->stream));
     return PRF_OK;
+}
+
+uint64_t prf_tile_positions(void) { return PRF_TILE; }
+
+int prf_genome_tile_classes(const prf_genome *g, uint32_t contig, uint8_t *dst, uint64_t capacity, uint64_t *n_tiles) {
+    if (!g || !n_tiles || contig >= g->base.size() || (capacity && !dst)) return fail(PRF_EINVAL, "prf_genome_tile_classes: bad arguments");
+    const u64 t0 = g->base[contig] / PRF_TILE, n = (g->len[contig] + PRF_TILE - 1) / PRF_TILE;
+    *n_tiles = n;
+    for (u64 i = 0; i < n && i < capacity; i++) dst[i] = g->vp.h_class[t0 + i];
+    return PRF_OK;
+}
+
+static int genome_select_impl(prf_genome *g, const prf_part *parts, int n_parts) {
+    if (!g || n_parts < 0 || (n_parts > 0 && !parts)) return fail(PRF_EINVAL, "prf_genome_select: bad arguments");
+    prf_ctx *c = g->ctx;
+    HIPCHK(hipSetDevice(c->dev));
+    HIPCHK(hipStreamSynchronize(c->stream));  // no scan of this genome may be reading the old selection
+    if (n_parts == 0) {
+        g->sel_on = false;
+        return PRF_OK;
+    }
+    std::vector<std::pair<u64, u64>> tr;
+    u64 positions = 0;
+    for (int i = 0; i < n_parts; i++) {
+        const prf_part &p = parts[i];
+        if (p.contig >= g->base.size()) return fail(PRF_EINVAL, "prf_genome_select: part %d names contig %u of %zu", i, p.contig, g->base.size());
+        const u64 len = g->len[p.contig];
+        const u64 end = std::min<u64>(p.end, len);
+        if (p.begin % PRF_TILE != 0 || (end % PRF_TILE != 0 && end != len) || p.begin > end)
+            return fail(PRF_EINVAL, "prf_genome_select: part %d [%llu, %llu) of contig %u must begin on a multiple of %u and end on one or at "
+                        "the contig's end", i, (unsigned long long)p.begin, (unsigned long long)p.end, p.contig, PRF_TILE);
+        if (end == p.begin) continue;
+        const u64 t0 = g->base[p.contig] / PRF_TILE;
+        tr.emplace_back(t0 + p.begin / PRF_TILE, t0 + (end + PRF_TILE - 1) / PRF_TILE);
+        positions += end - p.begin;
+    }
+    std::sort(tr.begin(), tr.end());
+    std::vector<std::pair<u64, u64>> merged;
+    for (const auto &r : tr) {
+        if (!merged.empty() && r.first < merged.back().second)
+            return fail(PRF_EINVAL, "prf_genome_select: parts overlap");
+        if (!merged.empty() && r.first == merged.back().second) merged.back().second = r.second;
+        else merged.push_back(r);
+    }
+    std::vector<u32> list;
+    {
+        const std::vector<u32> &all = g->vp.h_list;  // ascending by tile
+        size_t i = 0;
+        for (const auto &r : merged) {
+            while (i < all.size() && (all[i] & ~PRF_LAUNCH_MIXED) < r.first) i++;
+            while (i < all.size() && (all[i] & ~PRF_LAUNCH_MIXED) < r.second) list.push_back(all[i++]);
+        }
+    }
+    if (!g->d_sel_list) HIPCHK(hipMalloc((void **)&g->d_sel_list, sizeof(u32) * std::max<size_t>(1, g->vp.h_list.size())));
+    if (!list.empty()) HIPCHK(hipMemcpy(g->d_sel_list, list.data(), sizeof(u32) * list.size(), hipMemcpyHostToDevice));
+    g->sel_n = (u32)list.size();
+    g->sel_flat = prf_flat_base(list.data(), list.size());
+    g->sel_positions = positions;
+    g->sel_tiles = std::move(merged);
+    g->sel_on = true;
+    return PRF_OK;
+}
+
+int prf_genome_select(prf_genome *g, const prf_part *parts, int n_parts) {
+    try {
+        return genome_select_impl(g, parts, n_parts);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_genome_select: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_genome_select: unexpected exception");
+    }
 }
 
 int prf_plan_describe(uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span, char *buf, uint64_t buf_len) {

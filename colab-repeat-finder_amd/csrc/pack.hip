@@ -69,6 +69,92 @@ __global__ __launch_bounds__(256) void prf_synth_kernel(uint8_t *__restrict__ as
     *reinterpret_cast<uint4 *>(asc + j0) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// ---- stand-in recipe 2 (colab-repeat-finder_amd/synth.py::standin2, integer arithmetic only, so that numpy and this kernel
+// agree bit for bit): uniform background; N at [0, n_head), [n - n_tail, n) and [gap_lo, gap_hi); the body
+// [n_head, n - n_tail) is cut into slots of 588 positions, each with ONE planted perfect tandem repeat whose motif is the
+// background at the repeat's own first k positions.
+__device__ __forceinline__ u64 prf_splitmix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u32 prf_background(u64 seed, u64 j) { return (u32)(prf_splitmix(seed + (j + 1ull) * 0x9E3779B97F4A7C15ull) >> 62); }
+
+struct prf_slot_repeat {
+    u64 p;       // first position
+    u32 k, span;
+};
+__device__ __forceinline__ prf_slot_repeat prf_slot_params(u64 seed, u64 body_lo, u64 slot) {
+    const u64 d = prf_splitmix((seed ^ 0xD1B54A32D192ED03ull) + (slot + 1ull) * 0x9E3779B97F4A7C15ull);
+    const u64 d2 = prf_splitmix(d + 0x9E3779B97F4A7C15ull);
+    const u32 u = (u32)(d >> 48), v = (u32)(d >> 24) & 0xFFFFFFu, w = (u32)d & 0xFFFFFFu, x = (u32)(d2 >> 32);
+    // motif size: the reference's golden chr22 BED histogram for 1..6 (95 %), a thin tail up to 50
+    u32 k;
+    if (u < 18412u) k = 1; else if (u < 29561u) k = 2; else if (u < 49738u) k = 3; else if (u < 58461u) k = 4;
+    else if (u < 61413u) k = 5; else if (u < 62268u) k = 6;
+    else { const u32 t = u - 62268u; k = 7u + (t * t * 44u) / (3268u * 3268u); }
+    // copies: 3 + geometric(0.67); thresholds floor(2^24 * 0.67^(i+1))
+    const u32 th[16] = {11240734u, 7531292u, 5045965u, 3380797u, 2265134u, 1517639u, 1016818u, 681268u,
+                        456449u, 305821u, 204900u, 137283u, 91979u, 61626u, 41289u, 27664u};
+    u32 copies = 3;
+#pragma unroll
+    for (int i = 0; i < 16; i++) copies += v < th[i] ? 1u : 0u;
+    u32 span = k * copies + w % k;
+    span = span > 500u ? 500u : span;
+    span = span < 10u ? 10u : span;
+    prf_slot_repeat r;
+    r.k = k;
+    r.span = span;
+    r.p = body_lo + slot * 588ull + (u64)(x % (588u - span));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void prf_standin2_kernel(uint8_t *__restrict__ asc, u64 n, u64 seed, u64 n_head, u64 n_tail,
+                                                            u64 gap_lo, u64 gap_hi) {
+    const u64 chunk = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 j0 = chunk * 16;
+    if (j0 >= n) return;
+    const u64 body_lo = n_head, body_hi = n - n_tail;
+    const u64 n_slots = (body_hi - body_lo) / 588ull;
+    // 16 consecutive positions touch at most two slots
+    u64 cur_slot = ~0ull;
+    prf_slot_repeat rep = {0, 1, 0};
+    u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u64 j = j0 + (u64)i;
+        u32 ch = (u32)'N';
+        if (j < n && j >= n_head && j < body_hi && !(j >= gap_lo && j < gap_hi)) {
+            u64 src = j;
+            const u64 slot = (j - body_lo) / 588ull;
+            if (slot < n_slots) {
+                if (slot != cur_slot) {
+                    cur_slot = slot;
+                    rep = prf_slot_params(seed, body_lo, slot);
+                }
+                if (j >= rep.p && j < rep.p + rep.span) src = rep.p + (j - rep.p) % rep.k;
+            }
+            ch = (0x54474341u >> (8 * prf_background(seed, src))) & 0xFFu;  // "ACGT"[code]
+        }
+        w[i >> 2] |= ch << (8 * (i & 3));
+    }
+    *reinterpret_cast<uint4 *>(asc + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+hipError_t prf_launch_standin2(hipStream_t s, uint8_t *asc, u64 n, u64 seed) {
+    if (n == 0) return hipSuccess;
+    const u64 n_head = n / 100 < 10000 ? n / 100 : 10000, n_tail = n_head;
+    u64 gap_lo = 0, gap_hi = 0;
+    if (n >= 1000000) {
+        gap_lo = n / 8 * 3 + 12345;
+        gap_hi = gap_lo + n / 25;
+    }
+    const u64 chunks = (n + 15) / 16;
+    hipLaunchKernelGGL(prf_standin2_kernel, dim3((u32)((chunks + 255) / 256)), dim3(256), 0, s, asc, n, seed, n_head, n_tail, gap_lo,
+                       gap_hi);
+    return hipGetLastError();
+}
+
 hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed) {
     if (n == 0) return hipSuccess;
     const u64 chunks = (n + 15) / 16;

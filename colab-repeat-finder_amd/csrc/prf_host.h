@@ -5,16 +5,15 @@
 #include "prf_device.h"
 
 // device counter block (u64 each)
-#define PRF_ROWS_TICKET_SHIFT 40  // PRF_CNT_ROWS: row cursor below this bit, finished workgroups from it up
-
 enum {
-    PRF_CNT_CAND = 0,     // generic path: phase-1 candidates
-    PRF_CNT_HITS = 1,     // generic path: rows
-    PRF_CNT_BADPOS = 2,   // packer: first unsupported symbol
-    PRF_CNT_HIT_OVF = 4,  // fused path: largest per-tile row demand above the slab capacity
-    PRF_CNT_ROWS = 5,     // fused path: [39:0] cursor of the compact row array, [63:40] workgroups finished (one
-                          // atomic per workgroup does both; the last workgroup hands the counters to the host)
-    PRF_CNT_SHARD0 = 8,   // fused path: candidate-record counts (statistics), sharded over 16 cache lines by tile
+    PRF_CNT_CAND = 0,      // generic path: phase-1 candidates
+    PRF_CNT_HITS = 1,      // generic path: rows
+    PRF_CNT_BADPOS = 2,    // packer: first unsupported symbol
+    PRF_CNT_UNSORTED = 3,  // fused path: a tile wrote rows past its LDS sort list -> the row array is not fully sorted
+    PRF_CNT_HIT_OVF = 4,   // fused path: largest per-tile row demand above the slab capacity
+    PRF_CNT_ROWS = 5,      // fused path: rows in the compact array (written by the gather kernel)
+    PRF_CNT_TICKET = 6,    // fused path: gather workgroups finished (the last one hands the counters to the host)
+    PRF_CNT_SHARD0 = 8,    // fused path: candidate-record counts (statistics), sharded over 16 cache lines by tile
     PRF_CNT_NSHARD = 16,
     PRF_CNT_SHARD_STRIDE = 8,
     PRF_SH_CAND = 1,
@@ -25,6 +24,8 @@ hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords,
                                   u64 *bad_pos);
 hipError_t prf_launch_fill_u64(hipStream_t s, u64 *p, u64 n, u64 v);
 hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed);
+// stand-in recipe 2 (synth.py::standin2): background + N blocks + one planted repeat per 588-position slot
+hipError_t prf_launch_standin2(hipStream_t s, uint8_t *asc, u64 n, u64 seed);
 
 hipError_t prf_launch_scan_generic(hipStream_t s, const prf_planes &pl, u64 w_begin, u64 w_end, u32 kmin, u32 kmax,
                                    u32 min_repeats, u32 min_span, u64 *cand, u64 cand_cap, u64 *counters);

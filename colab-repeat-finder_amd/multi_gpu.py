@@ -24,6 +24,50 @@ def plan_contig_shards(lengths, world):
     return [sorted(s) for s in shards]
 
 
+TILE_COST = (1.0, 1.6, 0.0)   # ordinary tile, tile with not-ACGT symbols in reach (three planes, verified on the global planes), all-N tile
+
+
+def plan_parts(lengths, world, tile, classes=None):
+    """Cut ONE genome into `world` shares of equal cost: returns, per rank, a list of (contig, begin, end) position ranges
+    cut at multiples of `tile` (prf_native.tile_positions()), in genome order -- what Genome.select() takes.  A contig
+    longer than a share is split; a row belongs to the part that holds its first position, so the shares' row sets are
+    disjoint and their union is the whole scan (include/prf.h, prf_genome_select).  classes: optional per-contig arrays of
+    per-tile cost classes (Genome.tile_classes); without them every tile costs the same."""
+    costs, owner, index = [], [], []
+    for c, n in enumerate(lengths):
+        nt = -(-n // tile)
+        if classes is not None:
+            cls = np.asarray(classes[c], dtype=np.int64)
+            assert len(cls) == nt
+            w = np.asarray(TILE_COST)[cls]
+        else:
+            w = np.ones(nt)
+        costs.append(w)
+        owner.append(np.full(nt, c, dtype=np.int64))
+        index.append(np.arange(nt, dtype=np.int64))
+    if not costs:
+        return [[] for _ in range(world)]
+    costs, owner, index = np.concatenate(costs), np.concatenate(owner), np.concatenate(index)
+    cum = np.concatenate(([0.0], np.cumsum(costs)))
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world)] + [len(costs)]
+    shares = []
+    for r in range(world):
+        lo, hi = cuts[r], max(cuts[r], cuts[r + 1])
+        parts = []
+        i = lo
+        while i < hi:
+            c = int(owner[i])
+            j = i
+            while j < hi and owner[j] == c:
+                j += 1
+            begin, end = int(index[i]) * tile, min(int(index[j - 1] + 1) * tile, lengths[c])
+            if end > begin:
+                parts.append((c, begin, end))
+            i = j
+        shares.append(parts)
+    return shares
+
+
 def rows_to_tensor(rows, capacity, torch, device):
     """(capacity+1, 3) int64 tensor: 24-byte rows as three int64 words, the row count in the last row."""
     t = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)

@@ -37,6 +37,10 @@ class _Contig(ctypes.Structure):
     _fields_ = [("ascii", ctypes.c_void_p), ("len", ctypes.c_uint64)]
 
 
+class _Part(ctypes.Structure):
+    _fields_ = [("contig", ctypes.c_uint32), ("begin", ctypes.c_uint64), ("end", ctypes.c_uint64)]
+
+
 class _Hit(ctypes.Structure):
     _fields_ = [("start", ctypes.c_uint64), ("end", ctypes.c_uint64), ("k", ctypes.c_uint32), ("contig", ctypes.c_uint32)]
 
@@ -49,7 +53,7 @@ class ScanStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_double), ("phase1_ms", ctypes.c_double), ("phase2_ms", ctypes.c_double),
                 ("positions", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
                 ("n_hits", ctypes.c_uint64), ("n_launches", ctypes.c_uint32), ("path", ctypes.c_uint32),
-                ("seq", ctypes.c_uint64)]
+                ("seq", ctypes.c_uint64), ("sorted_on_device", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -59,7 +63,7 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
-           "prf_scan_wait"]
+           "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -85,6 +89,10 @@ def load_library():
         lib.prf_genome_load.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(vp)]
         lib.prf_genome_synth.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
                                          ctypes.c_uint32, ctypes.POINTER(vp)]
+        lib.prf_genome_standin.argtypes = lib.prf_genome_synth.argtypes
+        lib.prf_tile_positions.restype = ctypes.c_uint64
+        lib.prf_genome_select.argtypes = [vp, ctypes.POINTER(_Part), ctypes.c_int]
+        lib.prf_genome_tile_classes.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_genome_free.argtypes = [vp]
         lib.prf_genome_free.restype = None
         lib.prf_genome_positions.argtypes = [vp]
@@ -179,6 +187,25 @@ class Genome:
         finally:
             lib.prf_free_hits(ctypes.byref(hits))
 
+    def select(self, parts):
+        """Restrict the following scans of this genome to `parts`: (contig, begin, end) position ranges cut at multiples
+        of tile_positions() (multi_gpu.plan_parts makes them).  None / []: the whole genome again."""
+        parts = list(parts or [])
+        arr = (_Part * max(1, len(parts)))()
+        for i, (c, b, e) in enumerate(parts):
+            arr[i].contig, arr[i].begin, arr[i].end = c, b, e
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_select(self._h, arr, len(parts)))
+
+    def tile_classes(self, contig):
+        """numpy uint8 array, one cost class per tile of the contig (0 ordinary, 1 not-ACGT in reach, 2 never scanned)."""
+        import numpy as np
+        n = ctypes.c_uint64(0)
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_tile_classes(self._h, contig, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.uint8)
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_tile_classes(self._h, contig, out.ctypes.data_as(ctypes.c_void_p), n.value,
+                                                                  ctypes.byref(n)))
+        return out[:n.value]
+
     def scan_async(self, kmin, kmax, min_repeats, min_span):
         """Enqueue a scan (at most two in flight); returns its serial number for Context.scan_wait()."""
         seq = ctypes.c_uint64(0)
@@ -221,6 +248,15 @@ class Context:
         sa = (ctypes.c_uint64 * max(1, n))(*seeds)
         g = ctypes.c_void_p()
         _check(self.lib, self.lib.prf_genome_synth(self._h, la, sa, n, kmax_hint, ctypes.byref(g)))
+        return Genome(self, g, n)
+
+    def standin(self, lens, seeds, kmax_hint):
+        """Contigs of the stand-in recipe 2 (synth.standin2) generated on the device."""
+        n = len(lens)
+        la = (ctypes.c_uint64 * max(1, n))(*lens)
+        sa = (ctypes.c_uint64 * max(1, n))(*seeds)
+        g = ctypes.c_void_p()
+        _check(self.lib, self.lib.prf_genome_standin(self._h, la, sa, n, kmax_hint, ctypes.byref(g)))
         return Genome(self, g, n)
 
     def scan(self, seqs, kmin, kmax, min_repeats, min_span, flags=SCAN_DEFAULT):
@@ -365,6 +401,10 @@ def write_bed(bed_path, entries, rows):
     _check(lib, lib.prf_write_bed(os.fsencode(bed_path), 0, names, arr, len(entries), ctypes.byref(hits), ctypes.byref(written)))
     counts = np.bincount(rows["contig"], minlength=len(entries)) if len(rows) else np.zeros(len(entries), dtype=np.int64)
     return [int(c) for c in counts]
+
+
+def tile_positions():
+    return int(load_library().prf_tile_positions())
 
 
 def plan_describe(kmin, kmax, min_repeats, min_span):

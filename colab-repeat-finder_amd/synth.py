@@ -94,7 +94,8 @@ _SLOT_SALT = np.uint64(0xD1B54A32D192ED03)
 # motif size 1..6: cumulative golden-BED histogram (20000, 12110, 21917, 9475, 3207, 929) scaled to 95 % of 2^16
 _K_CUM = np.array([18412, 29561, 49738, 58461, 61413, 62268], dtype=np.int64)
 # copies = 3 + geometric(ratio 0.67): v (24 bits) below floor(2^24 * 0.67^(i+1)) adds one copy, i = 0..15
-_COPY_TH = np.array([int((1 << 24) * 0.67 ** (i + 1)) for i in range(16)], dtype=np.int64)
+_COPY_TH = np.array([11240734, 7531292, 5045965, 3380797, 2265134, 1517639, 1016818, 681268, 456449, 305821, 204900, 137283,
+                     91979, 61626, 41289, 27664], dtype=np.int64)   # the same table in csrc/pack.hip
 
 
 def standin2_layout(n):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PRF_ABI_VERSION 1
+#define PRF_ABI_VERSION 2
 
 typedef enum prf_status {
     PRF_OK = 0,
@@ -65,7 +65,7 @@ typedef struct prf_hit {
 } prf_hit;
 
 typedef struct prf_hits {
-    prf_hit *rows; /* library-owned; sorted by (contig, start, end) like reference :81 */
+    prf_hit *rows; /* library-owned; sorted by (contig, start, end) like reference :81 (on the device, fused path) */
     uint64_t n;
 } prf_hits;
 
@@ -81,6 +81,8 @@ typedef struct prf_scan_stats {
     uint32_t n_launches;    /* kernel launches in the timed region                                       */
     uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel                        */
     uint64_t seq;           /* fused path: serial number of this scan on its context (prf_scan_timings)  */
+    uint32_t sorted_on_device; /* 1: the rows left the device sorted by (contig, start, end), no host sort   */
+    uint32_t reserved;
 } prf_scan_stats;
 
 /* prf_scan flags */
@@ -109,8 +111,31 @@ int prf_genome_load(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint
  * base j = "ACGT"[splitmix64(seed + (j+1)*0x9E3779B97F4A7C15) >> 62]. */
 int prf_genome_synth(prf_ctx *ctx, const uint64_t *lens, const uint64_t *seeds, int n_contigs, uint32_t kmax_hint,
                      prf_genome **out);
+/* The same with the stand-in recipe for a chromosome (synth.py::standin2; no genome FASTA exists offline): uniform
+ * background, N blocks at both ends and a centromere-like gap, one planted perfect tandem repeat per 588 positions. */
+int prf_genome_standin(prf_ctx *ctx, const uint64_t *lens, const uint64_t *seeds, int n_contigs, uint32_t kmax_hint,
+                       prf_genome **out);
 void prf_genome_free(prf_genome *g);
 uint64_t prf_genome_positions(const prf_genome *g);
+
+/* Sharding ONE resident genome over several GPUs (north_star: "contigs x motif-sizes shard embarrassingly"; the
+ * reference's analogue is the 500 kb interval fan-out of hail_batch_pipeline/run_hail_batch_pipeline.py:76-77).
+ * Every rank holds the genome and selects the parts it scans: position ranges of contigs, cut at multiples of
+ * prf_tile_positions().  A row belongs to the part that holds its first position, so the row sets of disjoint parts
+ * are disjoint and their union over a cover of the genome is exactly the whole scan -- no halo, no exchange, no
+ * repair step.  The selection stays in force for every following scan of the genome (synchronous or pipelined);
+ * n_parts == 0 selects the whole genome again.  prf_scan_stats.positions then counts the selected positions. */
+typedef struct prf_part {
+    uint32_t contig;
+    uint64_t begin; /* contig-local, a multiple of prf_tile_positions()                         */
+    uint64_t end;   /* exclusive; a multiple of prf_tile_positions(), or >= the contig's length */
+} prf_part;
+uint64_t prf_tile_positions(void);
+int prf_genome_select(prf_genome *g, const prf_part *parts, int n_parts);
+/* Cost classes of a contig's tiles, for planners: 0 = ordinary, 1 = not-ACGT symbols in reach (slower variant),
+ * 2 = nothing but not-ACGT (never scanned).  *n_tiles = ceil(len / prf_tile_positions()); at most `capacity` bytes
+ * are written. */
+int prf_genome_tile_classes(const prf_genome *g, uint32_t contig, uint8_t *dst, uint64_t capacity, uint64_t *n_tiles);
 
 /* The hot path on a resident genome: every k in [kmin,kmax], rows as reference :81.
  * Requires min_repeats >= 2 (PRF_EUNSUPPORTED otherwise: reference behaviour for

@@ -190,7 +190,7 @@ def test_very_long_runs_flush_the_candidate_lists(ctx):
     assert stats.path == 1
     got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
     assert got == [(0, 300_000, 1), (300_001, 380_001, 2)]
-    assert stats.n_candidates > 100_000
+    assert stats.n_candidates > 10_000 and stats.sorted_on_device == 0   # records are per (lane, motif size); rows of the flushes bypass the sort
 
 
 def test_row_slab_overflow_grows_the_slabs(ctx):
@@ -373,7 +373,7 @@ def test_config_c4_hg38_sized_genome_on_one_gpu(ctx):
     g = ctx.synth(HG38_LENS, seeds, 50)
     try:
         rows, stats = g.scan(1, 50, 3, 9)
-        assert stats.path == 1 and stats.positions == sum(HG38_LENS) and stats.n_launches == 1
+        assert stats.path == 1 and stats.positions == sum(HG38_LENS) and stats.n_launches == 2 and stats.sorted_on_device == 1
         contig = rows["contig"].astype(np.int64)
         starts = rows["start"].astype(np.int64)
         ends = rows["end"].astype(np.int64)
@@ -413,7 +413,7 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
     g = ctx.load([seq], 50)
     try:
         rows, st = g.scan(1, 50, 3, 9)
-        assert st.path == 1 and st.n_launches == 1 and st.phase1_ms > 0 and st.seq > 0
+        assert st.path == 1 and st.n_launches == 2 and st.phase1_ms > 0 and st.seq > 0 and st.sorted_on_device == 1
         seqs = []
         for _ in range(5):
             none, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_DEFER_TIMING, fetch=False)
@@ -430,8 +430,7 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
         host = buf.cpu().numpy()
         assert n == len(rows) and host[cap].tolist() == [n, 0, 0] and (host[n:cap] == -1).all()
         got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
-        got = got[np.lexsort((got["end"], got["start"], got["contig"]))]
-        assert np.array_equal(got, rows)
+        assert np.array_equal(got, rows)                     # the rows leave the device sorted: no host sort in between
         # pipelined scans: two in flight, collected one step late; rows of a collected scan through the hand-off
         pending, done = None, []
         for _ in range(7):
@@ -476,6 +475,115 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
     finally:
         ctx.set_row_sink(None, 0)
         g.free()
+
+
+def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
+    """The fused path sorts a tile's rows in LDS and the gather concatenates the tiles in position order (reference
+    perfect_repeat_finder.py:81 returns sorted rows): the raw device array equals the fetched rows.  Runs that start in the
+    last positions of a tile and whose first examined group lies in the next tile are reported by the tile that holds the
+    start (boundary pass): planted at many tile edges here.  A tile with more rows than its LDS list sorts on the host
+    (stats.sorted_on_device == 0) -- same rows."""
+    import synth
+    import torch
+    n = 3_000_000
+    seq = bytearray(synth.standin2(n, 3).tobytes())
+    rng = np.random.default_rng(12)
+    for t in range(1, 45):
+        k = int(rng.choice([8, 9, 12, 16, 17, 24, 31, 40, 50]))
+        back = int(rng.integers(1, 8 * (4 if 2 * k >= 39 else (2 if 2 * k >= 23 else 1))))
+        p = t * 65_536 - back
+        motif = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+        seq[p:p + 4 * k] = (motif * 4)
+    seq = bytes(seq)
+    g = ctx.load([seq, seq[1_000_000:1_400_000]], 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.sorted_on_device == 1
+        want = [(0, s, e, k) for s, e, k in oracle_rows(seq, 1, 50, 3, 9)] + \
+               [(1, s, e, k) for s, e, k in oracle_rows(seq[1_000_000:1_400_000], 1, 50, 3, 9)]
+        assert rows_as_tuples(rows) == want
+        buf = torch.zeros((len(rows) + 1, 3), dtype=torch.int64, device="cuda")
+        assert ctx.last_hits_to_device(buf.data_ptr(), len(rows)) == len(rows)
+        raw = np.ascontiguousarray(buf.cpu().numpy()[:len(rows)]).view(rows.dtype).reshape(-1)
+        assert np.array_equal(raw, rows)
+    finally:
+        g.free()
+    dense = (b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG") * 2500
+    rows, st = ctx.scan([dense], 1, 6, 3, 9)
+    assert st.sorted_on_device == 0 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(dense, 1, 6, 3, 9)
+
+
+def test_parts_of_one_genome_scanned_separately_add_up_to_the_whole_scan(ctx):
+    """prf_genome_select: every rank holds the genome and scans its parts (position ranges cut at tile multiples); a row
+    belongs to the part that holds its first position.  The union over 2, 3, 8 and 13 shares == the whole scan, on the
+    fused and on the generic path, with runs planted across every cut and N blocks around; a part list may be empty."""
+    import multi_gpu
+    import prf_native
+    import synth
+    tile = prf_native.tile_positions()
+    assert tile == 65_536
+    lens = [1_500_000, 70_000, 0, 900_001, 65_536, 131_072]
+    seqs = [bytearray(synth.standin2(n, 50 + i).tobytes()) for i, n in enumerate(lens)]
+    rng = np.random.default_rng(3)
+    for s in seqs:
+        for cut in range(tile, len(s), tile):
+            for k, back in ((1, 5), (3, 2), (7, 30), (12, 3), (20, 12), (50, 31), (33, 140)):
+                if rng.random() < 0.5:
+                    motif = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+                    body = motif * (300 // k + 4)
+                    s[cut - back:cut - back + len(body)] = body[:max(0, len(s) - (cut - back))]
+    seqs[0][5 * tile - 10:5 * tile + 10] = b"N" * 20
+    seqs = [bytes(s) for s in seqs]
+    g = ctx.load(seqs, 60)
+    try:
+        for flags in (prf_native.SCAN_DEFAULT, prf_native.SCAN_FORCE_GENERIC):
+            g.select(None)
+            whole, st = g.scan(1, 60, 3, 9, flags=flags)
+            assert st.positions == sum(lens) and len(whole) > 3_000
+            classes = [g.tile_classes(c) for c in range(len(lens))]
+            assert [len(c) for c in classes] == [-(-n // tile) for n in lens] and classes[0][4] == 1 and classes[0][0] == 1
+            for world, cls in ((2, None), (3, classes), (8, classes), (13, None)):
+                shares = multi_gpu.plan_parts(lens, world, tile, cls)
+                assert len(shares) == world
+                got, covered = [], 0
+                for parts in shares:
+                    g.select(parts)
+                    rows, st = g.scan(1, 60, 3, 9, flags=flags)
+                    assert st.positions == sum(e - b for _c, b, e in parts)
+                    covered += st.positions
+                    # rows start inside the parts that produced them
+                    assert all(any(c == int(r["contig"]) and b <= int(r["start"]) < e for c, b, e in parts) for r in rows)
+                    got.append(rows)
+                assert covered == sum(lens)
+                got = np.concatenate(got)
+                assert np.array_equal(got, whole), (world, flags)       # shares are in genome order: concatenation is sorted
+        g.select([(0, 0, tile)])
+        with pytest.raises(prf_native.PrfError):
+            g.select([(0, 100, tile)])                                    # not on a tile multiple
+        with pytest.raises(prf_native.PrfError):
+            g.select([(0, 0, 2 * tile), (0, tile, 3 * tile)])             # overlapping
+        g.select(None)
+        rows, _ = g.scan(1, 60, 3, 9)
+        assert np.array_equal(rows, whole)
+    finally:
+        g.free()
+
+
+def test_stand_in_genome_generated_on_the_device_equals_the_host_recipe(ctx):
+    """prf_genome_standin writes synth.standin2's contigs on the device (N blocks, one planted repeat per 588-position
+    slot): same rows as the host-generated bytes loaded over PCIe, and as the oracle on the small contig."""
+    import synth
+    lens, seeds = [2_300_017, 400_000, 12_345], [7, 8, 9]
+    g = ctx.standin(lens, seeds, 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.positions == sum(lens)
+    finally:
+        g.free()
+    host = [synth.standin2(n, s).tobytes() for n, s in zip(lens, seeds)]
+    rows2, _ = ctx.scan(host, 1, 50, 3, 9)
+    assert np.array_equal(rows, rows2) and len(rows) > 4_000
+    assert [(s, e, k) for c, s, e, k in rows_as_tuples(rows) if c == 1] == oracle_rows(host[1], 1, 50, 3, 9)
 
 
 def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):

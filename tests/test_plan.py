@@ -33,10 +33,14 @@ def check(kmin, kmax, r, span):
             assert k not in seen, (k, t, seen[k])
             seen[k] = t
     assert sorted(seen) == list(range(kmin, kmax + 1))
-    # the LDS image must be wide enough for the furthest row any task reads
-    reach = max([t["k0"] + 15 for t in plan["tasks"] if t["kind"] == 0] +
-                [(t["k0"] & ~3) + 4 * (((t["k0"] & 3) + 8 + t["kind"] - 1 + 3) // 4) - 1 for t in plan["tasks"] if t["kind"]])
-    assert plan["nc"] >= 64 + (24 + reach) // 32 and plan["lds_bytes"] <= 160 * 1024 // 3
+    # the LDS image must be wide enough for the furthest row of a lane's extended stream any task reads: a group task
+    # reads rows 24 + k0 .. 24 + k0 + 15 in its last block, an exact task the whole 16-byte slots of rows 0 .. 31 + M - 1 + k
+    reach = max([24 + t["k0"] + 15 for t in plan["tasks"] if t["kind"] == 0] +
+                [4 * ((32 + t["kind"] - 1 + t["k0"] + 3) // 4) - 1 for t in plan["tasks"] if t["kind"]])
+    assert plan["nc"] >= 64 + reach // 32 and plan["lds_bytes"] <= 160 * 1024 // 3
+    for t in plan["tasks"]:
+        if t["kind"]:
+            assert t["k0"] <= t["kind"] <= 14        # exact tasks are compiled per (k, M), k <= M < 15
     return plan
 
 
