@@ -1,29 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the perfect-tandem-repeat scan on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22|chr1|random|hg38-random]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: ONE kernel launch (scan +
-verify + compaction of the rows into one array in HBM + counters), row count back on the host -- on a genome
-that is already packed and resident in HBM when the timed region starts.  At N = 1 two scans are in flight (prf_scan_genome_async / prf_scan_wait): scan i+1 is
-enqueued before scan i is collected, so its launch and the host's share overlap the kernel of scan i; all K scans
-are collected -- row count on the host, checked -- inside the timed region (--no-pipeline: one at a time).
-Workload (BASELINE.json configs[1]): a
-chr22-sized contig (50 818 468 bp), motif sizes 1-50, min_repeats 3, min_span 9.  No genome FASTA exists
-offline, so the contig is the synthetic stand-in of colab-repeat-finder_amd/synth.py (hg38-like N blocks,
-~1.8 k planted repeats per Mbp, uniform ACGT elsewhere).
+A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: two back-to-back launches on one stream
+(the fused scan+verify kernel: rows sorted per 65536-position tile; the row gather: one compact array sorted by
+(contig, start, end) + counters posted to the host), row count back on the host -- on a genome that is already packed and
+resident in HBM when the timed region starts.  At N = 1 two scans are in flight
+(prf_scan_genome_async / prf_scan_wait): scan i+1 is enqueued before scan i is collected; all K scans are collected --
+row count on the host, checked -- inside the timed region (--no-pipeline: one at a time).
 
-N > 1: one process per GPU; every rank scans its own chr22-sized contig (seed 22 + rank; weak scaling, no
-data-path collective) and the rows are then concatenated on rank 0 with one padded RCCL gather, inside
-the timed region (a communication thread issues the gathers from a ring of 4 send buffers while the main
-thread scans on: the gather of step i overlaps the scans of the following steps; every gather has completed
-when the timed region ends).
+Workload (default = the configuration BASELINE.json's metric is quoted on): hg38 -- 25 contigs with the hg38
+primary-assembly lengths (3 088 286 401 bp), motif sizes 1-50, min_repeats 3, min_span 9.  No genome FASTA exists offline, so
+the contigs follow the stand-in recipe of colab-repeat-finder_amd/synth.py::standin2 (uniform background, N blocks at both
+ends and a centromere-like gap, one planted perfect tandem repeat per 588 positions: ~1.8 k rows / Mbp like the reference's
+golden chr22 BED), generated ON the device (prf_genome_standin) so nothing crosses PCIe.  Other workloads:
+chr22 (BASELINE configs[1], 50 818 468 bp), chr1 (configs[2], 248 956 422 bp), random (configs[4]: ONE contig of 10^10 bp
+uniform ACGT, seed 2026, motif 1-100), hg38-random (the hg38 lengths, uniform ACGT).
 
-Rank 0 prints ONE JSON line.  `value` is whole-job Gbp/s from the wall clock (max over ranks); the
-`roofline` object prices the dominant kernel with the HIP events recorded around each of its launches in
-the timed region on the library's stream (read after the loop, prf_scan_timings); `cpu_baseline` is the CPU oracle (a C restatement of the reference, oracle/prf_oracle.c) timed on
-a bounded sample of the same workload on this host.
+N > 1 is STRONG scaling on the same workload: one process per GPU, every rank holds the whole genome and scans its share
+of it (multi_gpu.plan_parts: position ranges cut at tile multiples, balanced by tile cost; a row belongs to the share that
+holds its first position, so no halo and no exchange), then the rows are concatenated on rank 0 with one padded RCCL
+gather per step, inside the timed region (a communication thread issues the gathers from a ring of send buffers while the
+main thread scans on; every gather has completed when the timed region ends).
+
+Rank 0 prints ONE JSON line.  `value` is whole-job Gbp/s from the wall clock (max over ranks); the `roofline` object prices
+the dominant kernel (prf_vscan_kernel) with the HIP events recorded around each of its launches in the timed region on the
+library's stream (read after the loop, prf_scan_timings_split); `cpu_baseline` is the CPU oracle (a C restatement of the
+reference, oracle/prf_oracle.c) timed on a bounded sample of the same workload on this host: one thread, and all host cores.
 """
 import argparse
 import json
@@ -44,7 +49,7 @@ HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
-def pmc_traffic(length, kmin, kmax):
+def pmc_traffic(workload, kmin, kmax):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
     None if no committed measurement matches this workload."""
@@ -54,48 +59,100 @@ def pmc_traffic(length, kmin, kmax):
     try:
         with open(path) as f:
             for rec in json.load(f):
-                if rec["length"] == length and rec["kmin"] == kmin and rec["kmax"] == kmax:
+                if rec.get("workload") == workload and rec["kmin"] == kmin and rec["kmax"] == kmax:
                     return rec["hbm_bytes_per_launch"]
     except (ValueError, KeyError):
         pass
     return None
 
 
-def cpu_baseline(seq_bytes, kmin, kmax, min_repeats, min_span, sample_bp):
-    """Oracle (kind 'port': C restatement of the reference's state machine), 1 thread, bounded sample."""
+def _oracle_chunk(job):
     from oracle import prf_oracle
-    n_lead = len(seq_bytes) - len(seq_bytes.lstrip(b"N"))
-    sample = seq_bytes[n_lead:n_lead + sample_bp]
+    seq, kmin, kmax, r, span = job
     t0 = time.perf_counter()
-    rows = prf_oracle.detect_rows(sample, kmin, kmax, min_repeats, min_span)
-    dt = time.perf_counter() - t0
-    return {"value": len(sample) / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(sample)} non-N bp of the workload, motif {kmin}-{kmax}, {len(rows)} rows, {dt:.1f} s "
-                      f"single-thread C oracle (the pure-Python reference runs ~0.018 Mbp/s at motif 1-50, BASELINE.md)"}
+    n = len(prf_oracle.detect_rows(seq, kmin, kmax, r, span))
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(sample, kmin, kmax, min_repeats, min_span, what):
+    """Oracle (kind 'port': C restatement of the reference's state machine) on a bounded sample: one thread on the
+    whole sample, then every host core on its own slice of it (the reference's own parallel strategy is independent
+    interval jobs, one CPU each: hail_batch_pipeline/run_hail_batch_pipeline.py:101)."""
+    import multiprocessing as mp
+    n_rows, dt = _oracle_chunk((sample, kmin, kmax, min_repeats, min_span))
+    cores = max(1, len(os.sched_getaffinity(0)))
+    out = {"value": len(sample) / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
+           "sample": f"{what}, motif {kmin}-{kmax}, {n_rows} rows, {dt:.1f} s single-thread C oracle (the pure-Python "
+                     f"reference runs ~0.018 Mbp/s at motif 1-50, BASELINE.md)"}
+    if cores > 1:
+        step = -(-len(sample) // cores)
+        jobs = [(sample[i:i + step], kmin, kmax, min_repeats, min_span) for i in range(0, len(sample), step)]
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_oracle_chunk, jobs)
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": len(sample) / wall / 1e9, "unit": "Gbp/s", "cores": cores,
+                            "note": f"{len(jobs)} processes of the oracle, one slice of the sample each, {wall:.1f} s wall"}
+    return out
+
+
+def build_workload(args, ctx, synth):
+    """-> (genome, lens, name, description, host_sample(fn or None))"""
+    w = args.workload
+    if w == "hg38":
+        lens = HG38_LENS
+        seeds = [1000 + i for i in range(len(lens))]
+        g = ctx.standin(lens, seeds, args.kmax)
+        desc = (f"hg38-shaped genome: 25 contigs with the hg38 primary-assembly lengths ({sum(lens)} bp), stand-in recipe "
+                "(synth.standin2: uniform background, N blocks, one planted repeat per 588 positions) generated on the device")
+        sample = lambda n: synth.standin2(lens[0], seeds[0], 10_000, n).tobytes()
+        return g, lens, desc, sample, "first %d bp behind the leading N block of contig 0"
+    if w == "chr1":
+        lens = [synth.CHR1_LEN if not args.length else args.length]
+        g = ctx.standin(lens, [1], args.kmax)
+        desc = f"hg38 chr1-sized contig ({lens[0]} bp), stand-in recipe (synth.standin2) generated on the device"
+        return g, lens, desc, (lambda n: synth.standin2(lens[0], 1, 10_000, n).tobytes()), "first %d bp behind the leading N block"
+    if w == "chr22":
+        length = args.length or synth.CHR22_LEN
+        n_head = 10_510_000 if length >= 20_000_000 else length // 10
+        seq = synth.chr_standin(length=length, seed=22, n_head=n_head, n_tail=min(10_000, length // 100)).tobytes()
+        g = ctx.load([seq], args.kmax)
+        desc = f"chr22-sized synthetic stand-in contig ({length} bp; hg38-like N blocks, planted repeats; synth.chr_standin)"
+        return g, [length], desc, (lambda n: seq[n_head:n_head + n]), "first %d non-N bp"
+    if w == "random":
+        lens = [args.length or 10_000_000_000]
+        g = ctx.synth(lens, [2026], args.kmax)                     # generated in HBM, nothing crosses PCIe
+        desc = f"ONE contig of {lens[0]} bp uniform random ACGT (seed 2026), generated on the device"
+        from oracle import prf_oracle
+        return g, lens, desc, (lambda n: prf_oracle.synth(n, 2026)), "first %d bp"
+    lens = HG38_LENS                                                # hg38-random
+    seeds = [1000 + i for i in range(len(lens))]
+    g = ctx.synth(lens, seeds, args.kmax)
+    desc = f"25 contigs with the hg38 primary-assembly lengths ({sum(lens)} bp) of uniform random ACGT generated on the device"
+    from oracle import prf_oracle
+    return g, lens, desc, (lambda n: prf_oracle.synth(n, seeds[0])), "first %d bp of contig 0"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--length", type=int, default=0, help="contig length per GPU (default: chr22, 50 818 468)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["hg38", "chr22", "chr1", "random", "hg38-random"], default="hg38")
+    ap.add_argument("--length", type=int, default=0, help="contig length for chr22 / chr1 / random (default: the config's own)")
     ap.add_argument("--kmin", type=int, default=1)
-    ap.add_argument("--kmax", type=int, default=50)
+    ap.add_argument("--kmax", type=int, default=0, help="default 50 (100 for --workload random: BASELINE configs[4])")
     ap.add_argument("--min-repeats", type=int, default=3)
     ap.add_argument("--min-span", type=int, default=9)
     ap.add_argument("--cpu-sample-bp", type=int, default=12_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="N=1: wait for every scan before the next is enqueued (default: two scans in flight, "
-                         "prf_scan_genome_async / prf_scan_wait)")
-    ap.add_argument("--workload", choices=["chr22", "random", "hg38"], default="chr22",
-                    help="chr22: the default stand-in contig (BASELINE config C2, the headline); random: uniform ACGT "
-                         "generated on the device (config C5 is --workload random --length 1250000000 --kmax 100); "
-                         "hg38: 25 contigs with the hg38 primary-assembly lengths (3.09 Gbp of random ACGT generated "
-                         "on the device), dealt to the ranks longest first (config C4's shape; strong scaling)")
+                    help="N=1: wait for every scan before the next is enqueued (default: two scans in flight)")
+    ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the rows to rank 0 every this many steps")
     args = ap.parse_args()
+    if not args.kmax:
+        args.kmax = 100 if args.workload == "random" else 50
 
     import numpy as np
     import torch
@@ -122,30 +179,27 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    length = args.length or synth.CHR22_LEN
-    n_head = 10_510_000 if length >= 20_000_000 else length // 10
     ctx = prf_native.Context(dev_index)
-    total_bp = length * world
-    if args.workload == "hg38":
-        import multi_gpu
-        mine = multi_gpu.plan_contig_shards(HG38_LENS, world)[rank]          # what scan_contigs_sharded() does
-        genome = ctx.synth([HG38_LENS[i] for i in mine], [1000 + i for i in mine], args.kmax)
-        seq = None
-        length = sum(HG38_LENS[i] for i in mine)                             # this rank's positions
-        total_bp = sum(HG38_LENS)
-    elif args.workload == "random":
-        genome = ctx.synth([length], [22 + rank], args.kmax)        # generated in HBM, nothing crosses PCIe
-        seq = None
-    else:
-        seq = synth.chr_standin(length=length, seed=22 + rank, n_head=n_head, n_tail=min(10_000, length // 100)).tobytes()
-        genome = ctx.load([seq], args.kmax)
-    # the HIP events of every scan are read after the timed loop (prf_scan_timings), not waited for inside it
+    genome, lens, desc, sample_fn, sample_what = build_workload(args, ctx, synth)
+    total_bp = sum(lens)
     flags = prf_native.SCAN_FORCE_GENERIC if args.generic else prf_native.SCAN_DEFER_TIMING
     scan = lambda fetch: genome.scan(args.kmin, args.kmax, args.min_repeats, args.min_span, flags=flags, fetch=fetch)
 
-    # one untimed full scan: sizes the scratch buffers, gives the row count used to size the gather
+    rows_whole = None
+    shares = None
+    if world > 1:
+        import multi_gpu
+        if rank == 0:                                   # untimed: the whole scan on one GPU, to check the gathered rows against
+            rows_whole, _ = scan(True)
+        tile = prf_native.tile_positions()
+        classes = [genome.tile_classes(c) for c in range(len(lens))]
+        shares = multi_gpu.plan_parts(lens, world, tile, classes)
+        genome.select(shares[rank])
+
+    # one untimed full scan of this rank's share: sizes the scratch buffers, gives the row count used to size the gather
     rows, st0 = scan(True)
     n_rows_local = len(rows)
+    my_bp = int(st0.positions)
     gather_cap = None
     if world > 1:
         import queue
@@ -162,7 +216,7 @@ def main():
         free_q, work_q = queue.Queue(), queue.Queue()
         for b in range(NBUF):
             free_q.put(b)
-        comm_state = {"last": None, "error": None}
+        comm_state = {"last": None, "error": None, "gather_s": [], "n": 0}
 
         def comm_loop():
             try:
@@ -170,14 +224,18 @@ def main():
                 comm_stream = torch.cuda.Stream()
                 with torch.cuda.stream(comm_stream):
                     while True:
-                        b = work_q.get()
-                        if b is None:
+                        item = work_q.get()
+                        if item is None:
                             return
-                        if sends[b] is not send_devs[b]:
-                            sends[b].copy_(send_devs[b])                     # gloo rehearsal only
-                        dist.gather(sends[b], recvs[b], dst=0)
-                        comm_stream.synchronize()                            # the buffer may be refilled now
-                        comm_state["last"] = b
+                        b, do_gather = item
+                        if do_gather:
+                            t0 = time.perf_counter()
+                            if sends[b] is not send_devs[b]:
+                                sends[b].copy_(send_devs[b])                 # gloo rehearsal only
+                            dist.gather(sends[b], recvs[b], dst=0)
+                            comm_stream.synchronize()                        # the buffer may be refilled now
+                            comm_state["gather_s"].append(time.perf_counter() - t0)
+                            comm_state["last"] = b
                         free_q.put(b)
             except BaseException as exc:                                     # surfaces in fence()
                 comm_state["error"] = exc
@@ -185,7 +243,6 @@ def main():
 
         comm_thread = threading.Thread(target=comm_loop, name="prf-gather", daemon=True)
         comm_thread.start()
-        in_flight = [0]
 
     def take_buffer():
         b = free_q.get()
@@ -193,12 +250,15 @@ def main():
             raise RuntimeError("gather thread failed") from comm_state["error"]
         return b
 
+    step_no = [0]
+
     def step():
         if world > 1:
             b = take_buffer()                                                # blocks only if all NBUF gathers are pending
-            ctx.set_row_sink(send_devs[b].data_ptr(), gather_cap - 1)       # the kernel compacts the rows straight into the
-            _, st = scan(False)                                             # send buffer and writes the count record
-            work_q.put(b)
+            ctx.set_row_sink(send_devs[b].data_ptr(), gather_cap - 1)       # the gather kernel compacts the rows straight into
+            _, st = scan(False)                                             # the send buffer and writes the count record
+            step_no[0] += 1
+            work_q.put((b, step_no[0] % args.gather_every == 0))
         else:
             _, st = scan(False)
         return st
@@ -215,7 +275,7 @@ def main():
 
     def run_pipelined(n):
         """n steps with two scans in flight: scan i+1 is enqueued before scan i is collected, so its launch and the
-        host's share overlap the kernel of scan i.  Every scan is collected (row count checked) inside the call."""
+        host's share overlap the kernels of scan i.  Every scan is collected (row count checked) inside the call."""
         out, pending = [], None
         for _ in range(n):
             s = genome.scan_async(args.kmin, args.kmax, args.min_repeats, args.min_span)
@@ -233,13 +293,13 @@ def main():
         for _ in range(args.warmup):
             step()
     fence()
-    p1_ms, p2_ms, seqs = [], [], []
+    if world > 1:
+        comm_state["gather_s"].clear()
+    seqs = []
+    p1_ms, p2_ms = [], []
     t0 = time.perf_counter()
     if pipelined:
-        for st in run_pipelined(args.steps):
-            p1_ms.append(0.0)
-            p2_ms.append(0.0)
-            seqs.append(st.seq)
+        seqs = [st.seq for st in run_pipelined(args.steps)]
     else:
         for _ in range(args.steps):
             st = step()
@@ -248,12 +308,16 @@ def main():
             seqs.append(st.seq)
     fence()
     elapsed = time.perf_counter() - t0
-    if st0.path == 1:
+    scan_ms = gather_kernel_ms = None
+    if st0.path == 1 and st0.n_launches:
         # fused path: kernel durations from the HIP events recorded around each launch of the timed region (the
         # last TIMING_RING steps if there were more)
         tail = seqs[-prf_native.TIMING_RING:]
-        p1_ms = ctx.scan_timings(tail[0], len(tail))
-        p2_ms = [0.0]
+        scan_ms, gather_kernel_ms = ctx.scan_timings_split(tail[0], len(tail))
+        p1 = float(np.mean(scan_ms))
+    else:
+        p1 = float(np.mean(p1_ms)) if p1_ms else 0.0
+    kernel_ms_ranks = [p1]
     if world > 1:
         t = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,63 +325,66 @@ def main():
         tot = torch.tensor([n_rows_local], device=tdev, dtype=torch.int64)
         dist.all_reduce(tot)
         n_rows_total = int(tot.item())
+        km = [torch.zeros(1, device=tdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([p1], device=tdev, dtype=torch.float64))
+        kernel_ms_ranks = [float(x.item()) for x in km]
     else:
         n_rows_total = n_rows_local
 
     gathered_ok = None
-    if world > 1 and rank == 0:
-        # the last gather must hold every rank's rows: counts add up and rank 0's part equals its own fetched rows
+    if world > 1 and rank == 0 and comm_state["last"] is not None:
+        # the last gather must hold every rank's rows; the shares are in genome order, so their concatenation IS the
+        # whole scan's sorted row array
         recv = recvs[comm_state["last"]]
         counts = [int(r[gather_cap - 1, 0].item()) for r in recv]
-        mine = recv[0][:counts[0]].cpu().numpy().view(np.uint8).reshape(-1, 24)
-        ref = np.ascontiguousarray(rows).view(np.uint8).reshape(-1, 24)
-        order = lambda a: a[np.lexsort(a.T[::-1])]
-        gathered_ok = bool(sum(counts) == n_rows_total and counts[0] == n_rows_local and np.array_equal(order(mine), order(ref)))
+        parts = [np.ascontiguousarray(r[:c].cpu().numpy()).view(rows.dtype).reshape(-1) for r, c in zip(recv, counts)]
+        got = np.concatenate(parts)
+        gathered_ok = bool(sum(counts) == n_rows_total and np.array_equal(got, rows_whole))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bp / (elapsed / args.steps) / 1e9
-        p1 = float(np.mean(p1_ms))
         # algorithmic bytes per launch of the dominant kernel: the 2-bit input once for all k,
-        # plus the 24-byte rows
-        bytes_alg = (length + 3) // 4 + 24 * n_rows_local
-        achieved = bytes_alg / (p1 * 1e-3) / 1e9
+        # plus the 24-byte rows -- of this rank's share
+        bytes_alg = (my_bp + 3) // 4 + 24 * n_rows_local
+        achieved = bytes_alg / (p1 * 1e-3) / 1e9 if p1 else 0.0
         hbm_meas = ctx.measure_hbm_read(1 << 30, 5)
         out = {
             "metric": f"Gbp/s scanned (motif {args.kmin}-{args.kmax})", "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if args.workload == "hg38" else "weak", "vs_baseline": None, "dtype": "u64 bitplanes (2-bit bases)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 bit planes (2-bit bases)",
             "data": "synthetic",
-            "config": {"workload": (f"chr22-sized synthetic stand-in contig per GPU ({length} bp; hg38-like N blocks, "
-                                    "planted repeats)" if args.workload == "chr22" else
-                                    f"uniform random ACGT contig per GPU ({length} bp, generated on the device)"
-                                    if args.workload == "random" else
-                                    f"25 contigs with the hg38 primary-assembly lengths ({total_bp} bp of random ACGT "
-                                    f"generated on the device) dealt to {world} rank(s) longest first, rank 0 holds {length} bp") +
-                                   f", motif {args.kmin}-{args.kmax}, min_repeats {args.min_repeats}, "
+            "config": {"workload": f"{args.workload}: {desc}; motif {args.kmin}-{args.kmax}, min_repeats {args.min_repeats}, "
                                    f"min_span {args.min_span}; genome packed + resident in HBM before the timed region",
+                       "positions_total": total_bp, "positions_rank0": my_bp,
                        "kernel_path": "generic" if st0.path == 0 else "vertical",
-                       "rows_per_gpu": n_rows_local, "rows_total": n_rows_total,
-                       "candidates_per_gpu": int(st0.n_candidates),
+                       "rows_rank0": n_rows_local, "rows_total": n_rows_total,
+                       "rows_sorted_on_device": bool(st0.sorted_on_device),
+                       "candidate_records_rank0": int(st0.n_candidates),
                        "steps_in_flight": 2 if pipelined else 1,
-                       "multi_gpu": ("one contig per rank, no data-path collective; one padded RCCL gather of rows to rank 0"
-                                     f" (gather verified: {gathered_ok})") if world > 1 else "n/a"},
+                       "multi_gpu": ({"sharding": "every rank holds the genome and scans its share of the tiles (prf_genome_select); "
+                                                  "no data-path collective",
+                                      "gather": f"one padded RCCL gather of 24-byte rows to rank 0 every {args.gather_every} step(s), "
+                                                "overlapped with the following scans",
+                                      "gather_verified": gathered_ok,
+                                      "gather_ms_mean": round(float(np.mean(comm_state["gather_s"])) * 1e3, 4) if comm_state["gather_s"] else None,
+                                      "gather_rows_per_rank_max": gather_cap - 1,
+                                      "scan_kernel_ms_per_rank": [round(x, 5) for x in kernel_ms_ranks]} if world > 1 else "n/a")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(length, args.kmin, args.kmax) if (st0.path == 1 and args.workload == "chr22") else None,
-                         "kernel": "prf_vscan_kernel (fused scan + verify + row compaction: the only launch of a step)" if st0.path == 1 else "prf_scan_generic_kernel",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "traffic": pmc_traffic(args.workload, args.kmin, args.kmax) if (st0.path == 1 and world == 1) else None,
+                         "kernel": "prf_vscan_kernel (fused scan + verify + per-tile sorted rows)" if st0.path == 1 else "prf_scan_generic_kernel",
                          "kernel_ms": round(p1, 5),
+                         "gather_kernel_ms": round(float(np.mean(gather_kernel_ms)), 5) if gather_kernel_ms else None,
                          "algorithmic_bytes_per_launch": bytes_alg,
+                         # the same counting only the tiles that are launched (tiles of nothing but N are skipped)
+                         "achieved_nonN": round(((int(st0.tiles_launched) * 65536) // 4 + 24 * n_rows_local) / (p1 * 1e-3) / 1e9, 2) if p1 else None,
                          "measured_hbm_read_GBps": round(hbm_meas, 1),
                          "frac_of_measured_read": round(achieved / hbm_meas, 5)},
-            "device_ms": ({"fused_scan_verify_compact_kernel": round(p1, 5)} if st0.path == 1 else
-                          {"scan_kernel": round(p1, 5), "verify_kernel": round(float(np.mean(p2_ms)), 5)}),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N=1 only
-            if seq is None:
-                from oracle import prf_oracle
-                seq = prf_oracle.synth(min(HG38_LENS[0] if args.workload == 'hg38' else length, args.cpu_sample_bp),
-                                       1000 if args.workload == 'hg38' else 22 + rank)
-            out["cpu_baseline"] = cpu_baseline(seq, args.kmin, args.kmax, args.min_repeats, args.min_span,
-                                               args.cpu_sample_bp)
+            n = min(args.cpu_sample_bp, lens[0] - 20_000) if lens[0] > 40_000 else lens[0]
+            out["cpu_baseline"] = cpu_baseline(sample_fn(n), args.kmin, args.kmax, args.min_repeats, args.min_span,
+                                               (sample_what % n) + " of the workload")
         print(json.dumps(out), flush=True)
     if world > 1:
         ctx.set_row_sink(None, 0)

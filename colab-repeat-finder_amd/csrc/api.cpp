@@ -62,7 +62,7 @@ struct prf_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // fused path: one event pair per scan, in a ring, so that the kernel times of the last PRF_TIMING_RING scans can
     // be read after a timing loop (prf_scan_timings) instead of waiting for the events inside every scan
-    hipEvent_t ring[2 * PRF_TIMING_RING] = {};
+    hipEvent_t ring[3 * PRF_TIMING_RING] = {};  // per scan: before the scan kernel, between the two kernels, after the gather
     u64 *d_counters = nullptr;   // generic path + packer
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
@@ -85,6 +85,7 @@ struct prf_ctx {
         u64 *h_dev = nullptr;
         prf_hit_dev *rows = nullptr;
         u64 positions = 0;
+        u32 tiles = 0;
     } slot[2];
     u64 async_n = 0;
     u64 *h_async = nullptr;         // slot 1's counter block
@@ -93,9 +94,12 @@ struct prf_ctx {
     // fused (bit-sliced) path scratch: one row slab and one row count per launch slot (= scanned tile)
     prf_hit_dev *d_slabs = nullptr;
     u32 *d_slab_count = nullptr;
+    u32 *d_block_sum = nullptr;     // rows per PRF_GATHER_SLOTS launch slots; zero between scans (the gather clears it)
     u64 slab_slots = 0;
     u32 slab_cap = 0;
     bool last_sorted = true;        // the rows of the last scan left the device sorted by (contig, start, end)
+    u64 *stamps_buf = nullptr;      // diagnostic (PRF_STAMPS) builds only
+    u32 stamps_n = 0;
     // where the rows of the last scan are
     u64 last_nhits = 0;
 };
@@ -110,6 +114,7 @@ struct prf_genome {
     u32 kmax_hint = 0;
     u64 *H = nullptr, *L = nullptr, *X = nullptr;  // point PRF_FRONT_PAD words into their allocations
     u64 *d_base = nullptr;
+    uint4 *d_tile_info = nullptr;  // per tile: {contig, 0, contig base lo, hi}
     prf_vplanes vp;      // bit-sliced copy for scan_vertical
     // active selection (prf_genome_select): the scans of this genome cover only these tiles.  Off: the whole genome.
     bool sel_on = false;
@@ -193,6 +198,7 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_slabs);
     (void)hipFree(c->d_slab_count);
+    (void)hipFree(c->d_block_sum);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ring)
@@ -208,6 +214,7 @@ void prf_genome_free(prf_genome *g) {
     if (g->L) (void)hipFree(g->L - PRF_FRONT_PAD);
     if (g->X) (void)hipFree(g->X - PRF_FRONT_PAD);
     (void)hipFree(g->d_base);
+    (void)hipFree(g->d_tile_info);
     (void)hipFree(g->vp.VH);
     (void)hipFree(g->vp.VL);
     (void)hipFree(g->vp.VX);
@@ -289,6 +296,16 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     HIPCHK(hipMalloc((void **)&g->d_base, sizeof(u64) * (size_t)(n_contigs > 0 ? n_contigs : 1)));
     if (n_contigs > 0)
         HIPCHK(hipMemcpyAsync(g->d_base, g->base.data(), sizeof(u64) * (size_t)n_contigs, hipMemcpyHostToDevice, c->stream));
+    {   // the contig of every tile (contigs start on tile boundaries; the gap tiles behind a contig count as its own)
+        const u64 ntiles = g->G / PRF_TILE;
+        std::vector<uint4> info(ntiles, make_uint4(0, 0, 0, 0));
+        for (size_t ci = 0; ci < g->base.size(); ci++) {
+            const u64 t0 = g->base[ci] / PRF_TILE, t1 = ci + 1 < g->base.size() ? g->base[ci + 1] / PRF_TILE : ntiles;
+            for (u64 t = t0; t < t1; t++) info[t] = make_uint4((u32)ci, 0u, (u32)g->base[ci], (u32)(g->base[ci] >> 32));
+        }
+        HIPCHK(hipMalloc((void **)&g->d_tile_info, sizeof(uint4) * ntiles));
+        HIPCHK(hipMemcpy(g->d_tile_info, info.data(), sizeof(uint4) * ntiles, hipMemcpyHostToDevice));
+    }
     // bit-sliced copy for the vertical kernel (built from the ASCII while it is still resident)
     {
         int rc = prf_vertical_pack(c->stream, asc, g->G, &g->vp);
@@ -351,6 +368,10 @@ int prf_genome_standin(prf_ctx *c, const uint64_t *lens, const uint64_t *seeds, 
 static void reset_vcounters(prf_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemsetAsync(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64), c->stream);
+    if (c->d_block_sum)
+        (void)hipMemsetAsync(c->d_block_sum, 0,
+                             ((size_t)(c->slab_slots / PRF_GATHER_SLOTS + 1) + (size_t)(c->slab_slots / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER) + 2)) * sizeof(u32),
+                             c->stream);
     (void)hipStreamSynchronize(c->stream);
 }
 
@@ -391,19 +412,31 @@ static int wait_for_seq(prf_ctx *c, u64 seq, const u64 *block = nullptr) {
     }
 }
 
-int prf_scan_timings(prf_ctx *c, uint64_t first_seq, uint32_t n, float *kernel_ms) {
-    if (!c || (n && !kernel_ms)) return fail(PRF_EINVAL, "prf_scan_timings: bad arguments");
-    if (first_seq == 0 || first_seq + n - 1 > c->scan_seq || c->scan_seq - first_seq >= PRF_TIMING_RING)
+static int scan_timings_impl(prf_ctx *c, uint64_t first_seq, uint32_t n, float *total_ms, float *scan_ms, float *gather_ms) {
+    if (!c || first_seq == 0 || first_seq + n - 1 > c->scan_seq || c->scan_seq - first_seq >= PRF_TIMING_RING)
         return fail(PRF_EINVAL, "prf_scan_timings: scans %llu..%llu are not among the last %d fused scans of this context",
                     (unsigned long long)first_seq, (unsigned long long)(first_seq + n - 1), PRF_TIMING_RING);
     HIPCHK(hipSetDevice(c->dev));
     for (uint32_t i = 0; i < n; i++) {
         const u64 q = first_seq + i;
-        hipEvent_t ev_a = c->ring[2 * (q % PRF_TIMING_RING)], ev_b = c->ring[2 * (q % PRF_TIMING_RING) + 1];
+        hipEvent_t ev_a = c->ring[3 * (q % PRF_TIMING_RING)], ev_m = c->ring[3 * (q % PRF_TIMING_RING) + 1],
+                   ev_b = c->ring[3 * (q % PRF_TIMING_RING) + 2];
         HIPCHK(hipEventSynchronize(ev_b));
-        HIPCHK(hipEventElapsedTime(&kernel_ms[i], ev_a, ev_b));
+        if (total_ms) HIPCHK(hipEventElapsedTime(&total_ms[i], ev_a, ev_b));
+        if (scan_ms) HIPCHK(hipEventElapsedTime(&scan_ms[i], ev_a, ev_m));
+        if (gather_ms) HIPCHK(hipEventElapsedTime(&gather_ms[i], ev_m, ev_b));
     }
     return PRF_OK;
+}
+
+int prf_scan_timings(prf_ctx *c, uint64_t first_seq, uint32_t n, float *kernel_ms) {
+    if (!c || (n && !kernel_ms)) return fail(PRF_EINVAL, "prf_scan_timings: bad arguments");
+    return scan_timings_impl(c, first_seq, n, kernel_ms, nullptr, nullptr);
+}
+
+int prf_scan_timings_split(prf_ctx *c, uint64_t first_seq, uint32_t n, float *scan_ms, float *gather_ms) {
+    if (!c || (n && (!scan_ms || !gather_ms))) return fail(PRF_EINVAL, "prf_scan_timings_split: bad arguments");
+    return scan_timings_impl(c, first_seq, n, nullptr, scan_ms, gather_ms);
 }
 
 static int ensure_buffers(prf_ctx *c, u64 want_cand, u64 want_hits) {
@@ -428,14 +461,20 @@ static int ensure_slabs(prf_ctx *c, u64 nslots, u32 cap) {
     if (nslots > c->slab_slots || cap > c->slab_cap) {
         nslots = std::max<u64>(nslots, c->slab_slots);
         cap = std::max<u32>(cap, c->slab_cap);
+        HIPCHK(hipStreamSynchronize(c->stream));  // no scan in flight may still use the old buffers
         (void)hipFree(c->d_slabs);
         (void)hipFree(c->d_slab_count);
+        (void)hipFree(c->d_block_sum);
         c->d_slabs = nullptr;
         c->d_slab_count = nullptr;
+        c->d_block_sum = nullptr;
         c->slab_slots = 0;
         c->slab_cap = 0;
+        const size_t n_blocks = (size_t)(nslots / PRF_GATHER_SLOTS + 1) + (size_t)(nslots / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER) + 2);
         HIPCHK(hipMalloc((void **)&c->d_slabs, nslots * (u64)cap * sizeof(prf_hit_dev)));
         HIPCHK(hipMalloc((void **)&c->d_slab_count, nslots * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->d_block_sum, n_blocks * sizeof(u32)));
+        HIPCHK(hipMemset(c->d_block_sum, 0, n_blocks * sizeof(u32)));
         c->slab_slots = nslots;
         c->slab_cap = cap;
     }
@@ -451,22 +490,40 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
     a.H = g->H; a.L = g->L; a.X = g->X;
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
-    a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.slab_cap = c->slab_cap;
+    a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
+    a.super_off = (lv.n + PRF_GATHER_SLOTS - 1u) / PRF_GATHER_SLOTS;  // the gather's grid
     a.min_repeats = min_repeats; a.min_span = min_span;
-    a.contig_base = g->d_base; a.n_contigs = (u32)g->base.size();
+    a.tile_info = g->d_tile_info;
     a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
+    a.dbg = nullptr;
+#ifdef PRF_STAMPS
+    {
+        static u64 *dbg_buf = nullptr;
+        const size_t nu = (size_t)(1u << 18) * PRF_VMAX_WAVES * 16;  // up to 262144 tiles
+        if (!dbg_buf) HIPCHK(hipMalloc((void **)&dbg_buf, nu * sizeof(u64)));
+        if (lv.n <= (1u << 18)) {
+            HIPCHK(hipMemsetAsync(dbg_buf, 0, (size_t)lv.n * PRF_VMAX_WAVES * 16 * sizeof(u64), c->stream));
+            a.dbg = dbg_buf;
+            c->stamps_buf = dbg_buf;
+            c->stamps_n = lv.n;
+        }
+    }
+#endif
     a.plan = plan;
     prf_vgather_args ga;
-    ga.slabs = c->d_slabs; ga.slab_count = c->d_slab_count; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
+    ga.slabs = c->d_slabs; ga.slab_count = c->d_slab_count; ga.block_sum = c->d_block_sum; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
+    ga.super_off = a.super_off;
     ga.rows = rows; ga.rows_cap = rows_cap; ga.count_row = count_row;
     ga.counters = a.counters;
     ga.host_counters = host_counters_dev;
     ga.seq = ++c->scan_seq;
     ga.next_counters = c->d_vcounters + (size_t)(c->parity ^ 1u) * PRF_CNT_N;
     c->parity ^= 1u;
-    hipEvent_t ev_a = c->ring[2 * (ga.seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (ga.seq % PRF_TIMING_RING) + 1];
+    hipEvent_t ev_a = c->ring[3 * (ga.seq % PRF_TIMING_RING)], ev_m = c->ring[3 * (ga.seq % PRF_TIMING_RING) + 1],
+               ev_b = c->ring[3 * (ga.seq % PRF_TIMING_RING) + 2];
     HIPCHK(hipEventRecord(ev_a, c->stream));
     hipError_t le = prf_vertical_launch(c->stream, a);
+    if (le == hipSuccess) le = hipEventRecord(ev_m, c->stream);
     if (le == hipSuccess) le = prf_vertical_gather(c->stream, ga);
     if (le != hipSuccess) {
         reset_vcounters(c);
@@ -529,13 +586,29 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             rc = launch_fused(c, g, plan, min_repeats, min_span, c->sink ? c->sink : c->d_hits, c->sink ? c->sink_cap : c->hit_cap,
                               c->sink ? 1u : 0u, c->h_counters_dev, &seq);
             if (rc) return rc;
-            hipEvent_t ev_a = c->ring[2 * (seq % PRF_TIMING_RING)], ev_b = c->ring[2 * (seq % PRF_TIMING_RING) + 1];
+            hipEvent_t ev_a = c->ring[3 * (seq % PRF_TIMING_RING)], ev_b = c->ring[3 * (seq % PRF_TIMING_RING) + 2];
             // The scan is over for the host when the gather's last workgroup has posted the counter block and this
             // scan's serial number in mapped host memory: poll that word instead of waiting for the stream to drain
             // (the kernel's end-of-grid handshake, the event and the wake-up cost ~5 us).
             // Everything that consumes the rows is enqueued on the same stream, hence ordered after the kernels.
             rc = wait_for_seq(c, seq);
             if (rc) return rc;
+#ifdef PRF_STAMPS
+            if (const char *path = getenv("PRF_STAMPS_OUT")) {
+                fprintf(stderr, "[prf] plan: %u waves, %u tasks\n", plan.n_waves, plan.n_tasks);
+                for (u32 w = 0; w < plan.n_waves; w++)
+                    for (u32 ti = plan.wave_begin[w]; ti < plan.wave_begin[w + 1]; ti++)
+                        fprintf(stderr, "[prf]   wave %u slot %u: kind %u k0 %u valid %02x stride %u\n", w, ti - plan.wave_begin[w],
+                                plan.tasks[ti].kind, plan.tasks[ti].k0, plan.tasks[ti].valid, plan.tasks[ti].stride);
+                if (c->stamps_buf) {
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    const size_t nu = (size_t)c->stamps_n * PRF_VMAX_WAVES * 16;
+                    std::vector<u64> host(nu);
+                    HIPCHK(hipMemcpy(host.data(), c->stamps_buf, nu * sizeof(u64), hipMemcpyDeviceToHost));
+                    if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, nu, f); fclose(f); }
+                }
+            }
+#endif
             // a row sink is read by the caller on streams of its own: wait until every workgroup has copied its rows
             if (c->sink) HIPCHK(hipStreamSynchronize(c->stream));
             if (stats && !(flags & PRF_SCAN_DEFER_TIMING)) {
@@ -618,6 +691,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         stats->path = vs ? 1 : 0;
         stats->seq = vs && launches ? c->scan_seq : 0;
         stats->sorted_on_device = sorted_on_device ? 1u : 0u;
+        stats->tiles_launched = vs ? lv.n : 0u;
     }
     if ((flags & PRF_SCAN_NO_FETCH) || !out) return PRF_OK;
     if (nhits == 0) return PRF_OK;
@@ -714,6 +788,7 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
     }
     sl.seq = seq;
     sl.positions = lv.positions;
+    sl.tiles = lv.n;
     c->async_n++;
     *seq_out = seq;
     return PRF_OK;
@@ -746,6 +821,7 @@ int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->sorted_on_device = c->last_sorted ? 1u : 0u;
+        stats->tiles_launched = sl->tiles;
         stats->positions = sl->positions;
         stats->packed_bytes = (sl->positions + 3) / 4;
         stats->n_candidates = ncand;

@@ -9,6 +9,8 @@
 #define PRF_VMAX_K 480       // largest motif size the fused kernel takes (9-bit k field, LDS image width)
 #define PRF_VMAX_TASKS 80
 #define PRF_VMAX_WAVES 4
+#define PRF_GATHER_SLOTS 8u           // launch slots per workgroup of the row gather
+#define PRF_GATHER_SUPER 64u          // gather workgroups per second-level sum
 #define PRF_LAUNCH_MIXED 0x80000000u  // launch-list entry: the tile has not-ACGT positions in reach
 
 // Bit-sliced planes: see scan_vertical.hip for the layout.
@@ -31,7 +33,9 @@ struct prf_vtask {
     unsigned char kind;
     unsigned char valid;
     unsigned char stride;   // group tasks: examine every `stride`-th aligned group of 8 rows (1, 2 or 4)
-    unsigned char pad[3];
+    unsigned char pad;
+    unsigned short item0;   // group tasks: index of the task's first motif size among all motif sizes of group tasks;
+                            // exact tasks: index among the exact tasks
 };
 
 // Work plan of one scan (host-built from kmin,kmax,min_repeats,min_span): tasks grouped per wave.
@@ -43,6 +47,9 @@ struct prf_vplan {
     u32 nc;                                     // virtual lanes of the LDS image (64 + extra)
     u32 lds_bytes;
     u32 cof_words;                              // entries of the cofactor table staged in LDS (covers 0 .. kmax)
+    u32 n_group_k;                              // motif sizes scanned by group tasks (boundary items of a tile)
+    u32 n_exact;                                // exact tasks: motif sizes k_exact0 .. k_exact0 + n_exact - 1 (item0 = k - k_exact0)
+    u32 k_exact0;
 };
 
 // everything the fused kernel needs (passed by value)
@@ -54,11 +61,13 @@ struct prf_vscan_args {
     u32 flat_base;                 // != ~0u: entry i is the clean tile flat_base + i (no dependent load)
     prf_hit_dev *slabs;            // [launch slot][slab_cap]: the tile's rows, sorted by (start, end)
     u32 *slab_count;               // [launch slot]: rows the tile produced (> slab_cap: the slab overflowed)
+    u32 *block_sum;                // [launch slot / PRF_GATHER_SLOTS]: rows stored by those slots (zero when the kernel starts);
+    u32 super_off;                 // from block_sum[super_off] on: the same per PRF_GATHER_SLOTS * PRF_GATHER_SUPER slots
     u32 slab_cap;
     u32 min_repeats, min_span;
-    const u64 *contig_base;
-    u32 n_contigs;
+    const uint4 *tile_info;        // [tile]: {contig, 0, contig base lo, hi}
     u64 *counters;                 // this scan's counter block (zero when the kernel starts)
+    u64 *dbg;                      // diagnostic (PRF_STAMPS) builds only; nullptr otherwise
     prf_vplan plan;
 };
 
@@ -66,6 +75,8 @@ struct prf_vscan_args {
 struct prf_vgather_args {
     const prf_hit_dev *slabs;
     const u32 *slab_count;
+    u32 *block_sum;                // read, then cleared by the last workgroup
+    u32 super_off;
     u32 slab_cap;
     u32 n_launch;
     prf_hit_dev *rows;             // the compact row array, sorted by (contig, start, end) because the slabs are

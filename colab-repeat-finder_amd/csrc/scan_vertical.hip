@@ -53,7 +53,7 @@ constexpr int RG = T / 4;  // row groups of 4 rows = one 16-byte slot per lane
 constexpr int LIN_PRE = 1;                                    // linear window: words before the tile
 constexpr int LIN_POST = 24;                                  // ... and after it
 constexpr int LW = (int)PRF_TILE_WORDS + LIN_PRE + LIN_POST;  // words per plane in the LDS window
-constexpr int REC_PER_WAVE = 128;                             // candidate records per wave (LDS list)
+constexpr int REC_PER_WAVE = 96;                              // group-task candidate records per wave (LDS list)
 constexpr int MAX_WAVES = PRF_VMAX_WAVES;
 constexpr int NTH = 64 * MAX_WAVES;                           // threads per workgroup, always
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
@@ -81,8 +81,25 @@ __device__ __forceinline__ u64 make_rec(u32 lane, u32 k, u32 sc, u32 word) {
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
 constexpr int SMEM_HDR = 192;
 
+// LDS is addressed through explicit address-space pointers everywhere: a generic pointer that the compiler cannot trace back
+// to prf_smem becomes a flat_load, which is slower and waits on both memory counters.
 typedef u32 prf_u32x4 __attribute__((ext_vector_type(4)));  // (HIP's uint4 class cannot be copied out of an explicit address space)
 typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_cu4;
+typedef __attribute__((address_space(3))) prf_u32x4 prf_lds_u4;
+typedef __attribute__((address_space(3))) u64 prf_lds_u64;
+typedef __attribute__((address_space(3))) u32 prf_lds_u32;
+typedef __attribute__((address_space(3))) const u32 prf_lds_cu32;
+
+// Diagnostic build only (make STAMPS=1 -> libprf_stamps.so): per-wave s_memtime stamps at the phase boundaries, written
+// to a debug buffer that nothing else reads.  The product build has no stamp.
+#ifdef PRF_STAMPS
+#define PRF_STAMP(i)                                                                                               \
+    do {                                                                                                           \
+        if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PRF_STAMP(i) do { } while (0)
+#endif
 
 // what the verification step needs about the tile; lives at the start of LDS (filled by thread 0 while staging)
 struct TileCtx {
@@ -97,26 +114,54 @@ struct TileCtx {
     u32 min_repeats, min_span;
     u32 lin_off;              // byte offset of the linear window in LDS
     u32 has_lin;              // the linear window is staged (clean tiles)
+    u32 cof_off;              // byte offset of the cofactor table in LDS
+    u32 hotw_off;             // byte offset of the exact tasks' stream words in LDS: [exact task][lane], then (k | M << 16) per task
+    u32 n_exact;              // exact tasks of the plan: motif sizes k_exact0 .. k_exact0 + n_exact - 1, task index = k - k_exact0
+    u32 k_exact0;
 };
 static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
 
-__device__ __forceinline__ u32 *smem_rec_cnt() { return reinterpret_cast<u32 *>(prf_smem + 128); }          // [MAX_WAVES]
-__device__ __forceinline__ u32 *smem_rec_flushed() { return reinterpret_cast<u32 *>(prf_smem + 144); }      // [MAX_WAVES]
 __device__ __forceinline__ u32 *smem_row_cnt() { return reinterpret_cast<u32 *>(prf_smem + 160); }          // rows sent to the LDS list
 __device__ __forceinline__ u32 *smem_direct_cnt() { return reinterpret_cast<u32 *>(prf_smem + 164); }       // rows written straight to the slab
-__device__ __forceinline__ u64 *smem_row_keys() { return reinterpret_cast<u64 *>(prf_smem + SMEM_HDR); }
-__device__ __forceinline__ u32 *smem_row_ks() { return reinterpret_cast<u32 *>(prf_smem + SMEM_HDR + ROW_CAP_LDS * 8); }
+// the row list (lies where the image was): 32-bit sort keys, motif sizes, ends, ROW_CAP_LDS of each
+__device__ __forceinline__ prf_lds_u32 *smem_row_keys() { return (prf_lds_u32 *)(prf_smem + SMEM_HDR); }
+__device__ __forceinline__ prf_lds_u32 *smem_row_ks() { return (prf_lds_u32 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 4); }
+__device__ __forceinline__ prf_lds_u64 *smem_row_ends() { return (prf_lds_u64 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 8); }
 
-// One row.  to_lds: into the LDS list that is sorted at the end of the tile (key = start and end relative to the
-// tile, 24 + 40 bits); a full list, or a list that cannot be used yet (a wave emptying its record list in the
-// middle of the scan, while the image still lies there), sends the row straight to the slab, unsorted.
+// cof[k]: the cofactors k/p of the distinct primes p | k, one per byte, largest first (k <= 480 has at most 4
+// distinct primes and k/p <= 240).  The motif seq[a:a+k] is primitive iff it has none of these periods
+// (reference consists_of_perfect_repeats, utils/perfect_repeat_tracker.py:108-142, tries every divisor).
+// Entries 0 .. kmax of the scan are copied to LDS per tile: a table look, not a run-time division, per candidate.
+struct CofTable {
+    u32 v[PRF_VMAX_K + 4];
+    constexpr CofTable() : v{} {
+        for (u32 k = 2; k <= PRF_VMAX_K; k++) {
+            u32 rest = k, packed = 0, n = 0;
+            for (u32 p = 2; p <= rest; p++) {
+                if (rest % p) continue;
+                packed |= (k / p) << (8 * n++);
+                while (rest % p == 0) rest /= p;
+            }
+            v[k] = packed;
+        }
+    }
+};
+__constant__ const CofTable prf_cof_table{};
+
+// One row.  to_lds: into the LDS list that is sorted at the end of the tile.  Sort key: start in the tile (16 bits), then
+// length clipped to 16 bits -- exact, because of the rows that share a start at most one is longer than two motif sizes
+// (two periods on a long common stretch force their gcd, Fine and Wilf).  A full list, or a list that cannot be
+// used yet (a wave emptying its record list in the middle of the scan, while the image still lies there), sends the row
+// straight to the slab, unsorted.
 __device__ __forceinline__ void emit_row(const TileCtx &tc, bool to_lds, u64 a, u64 b, u32 k) {
     const u64 end = b + k;
     if (to_lds) {
         const u32 i = atomicAdd(smem_row_cnt(), 1u);
         if (i < (u32)ROW_CAP_LDS) {
-            smem_row_keys()[i] = ((a - tc.tile_base) << 40) | (end - tc.tile_base);
+            const u64 span = end - a;
+            smem_row_keys()[i] = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
             smem_row_ks()[i] = k;
+            smem_row_ends()[i] = end;
             return;
         }
     }
@@ -131,7 +176,12 @@ __device__ __forceinline__ void emit_row(const TileCtx &tc, bool to_lds, u64 a, 
     }
 }
 
-__device__ __forceinline__ prf_window_view make_view(const TileCtx &tc) {
+// One 64-position look: mismatch bits (1 = differs, or either side is not ACGT) of positions q .. q+63 against q+k ..,
+// served from the LDS window where it covers both sides, from the global planes elsewhere.  NOT inlined: verification is
+// a few looks per candidate in divergent code, and forty inlined copies of the look were 90 KB of kernel (the
+// instruction cache is shared by two CUs).
+__device__ __noinline__ u64 tile_mismatch64(u64 q, u32 k) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     prf_window_view view;
     view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
     view.w0 = tc.w0;
@@ -140,17 +190,39 @@ __device__ __forceinline__ prf_window_view make_view(const TileCtx &tc) {
     view.xz_hi = tc.xz_hi;
     view.x_in_lds = 0;
     view.P[0] = tc.H; view.P[1] = tc.L; view.P[2] = tc.X;
-    return view;
+    return view.mismatch64(q, k);
 }
 
 // run at motif size k, known to match up to `from`: where does it end?  (the guard gap guarantees an end)
-__device__ __forceinline__ u64 run_end(const prf_window_view &view, u64 from, u32 k) {
+__device__ __forceinline__ u64 run_end(u64 from, u32 k) {
     u64 b = from;
     for (;;) {
-        const u64 m2 = view.mismatch64(b, k);
+        const u64 m2 = tile_mismatch64(b, k);
         if (m2) return b + (u64)__builtin_ctzll(m2);
         b += 64;
     }
+}
+
+// Is seq[a : a+k] a whole number (>= 2) of copies of a shorter word?  (reference consists_of_perfect_repeats,
+// utils/perfect_repeat_tracker.py:108-142, tries every divisor.)  A word of length k has a proper divisor period iff it has
+// period k/p for some prime p | k: one period test per entry of cof[k].
+__device__ __forceinline__ bool motif_is_repeat(u64 a, u32 k) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
+    for (u32 cf = ((prf_lds_cu32 *)(prf_smem + tc.cof_off))[k]; cf; cf >>= 8) {
+        const u32 d = cf & 255u, need = k - d;  // period d: positions a .. a+need-1 equal the ones d later
+        bool has = true;
+        for (u32 off = 0; off < need; off += 64) {
+            u64 mm = tile_mismatch64(a + off, d);
+            const u32 left = need - off;
+            if (left < 64) mm &= (1ull << left) - 1ull;
+            if (mm) {
+                has = false;
+                break;
+            }
+        }
+        if (has) return true;
+    }
+    return false;
 }
 
 // Every candidate of motif size k that the flagged stream [sp, sp+32) owns, re-derived from the linear planes.
@@ -158,11 +230,12 @@ __device__ __forceinline__ u64 run_end(const prf_window_view &view, u64 from, u3
 //  sc >= 1 (group task, every S = 1 << (sc-1) th aligned group of 8 examined): every examined all-match group of the
 //          stream that is the FIRST examined all-match group of its run; the run is dropped if it starts before the
 //          tile (the previous tile reports it, see boundary_pass).
-__device__ __forceinline__ void verify_stream(const prf_window_view &view, const TileCtx &tc, u64 sp, u32 k, u32 sc, bool to_lds) {
+__device__ __noinline__ void verify_stream(u64 sp, u32 k, u32 sc, bool to_lds) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     const long long M = prf_min_matches(k, tc.min_repeats, tc.min_span);
     if (sc == 0) {
         // bit i of m = mismatch at position sp - 1 + i
-        const u64 m = sp ? view.mismatch64(sp - 1, k) : ((view.mismatch64(0, k) << 1) | 1ull);
+        const u64 m = sp ? tile_mismatch64(sp - 1, k) : ((tile_mismatch64(0, k) << 1) | 1ull);
         u64 r = ~m;  // bit i: positions i .. i+len-1 all match
         u32 len = 1;
         while (2 * len <= (u32)M) {
@@ -176,8 +249,8 @@ __device__ __forceinline__ void verify_stream(const prf_window_view &view, const
             st &= st - 1;
             const u64 a = sp - 1 + i;
             const u64 after = m >> i;  // bit j = mismatch at a + j, known for j < 64 - i
-            const u64 b = after ? a + (u64)__builtin_ctzll(after) : run_end(view, a + (64 - i), k);
-            if (!prf_vmotif_is_repeat(view, a, k)) emit_row(tc, to_lds, a, b, k);
+            const u64 b = after ? a + (u64)__builtin_ctzll(after) : run_end(a + (64 - i), k);
+            if (!motif_is_repeat(a, k)) emit_row(tc, to_lds, a, b, k);
         }
         return;
     }
@@ -186,7 +259,7 @@ __device__ __forceinline__ void verify_stream(const prf_window_view &view, const
     for (u32 j = 0; j < 4u; j += S) {
         const u64 p = sp + 8u * j;
         const u32 look = p >= back ? back : (u32)p;   // the arrays start less than `back` before p (first tile only)
-        const u64 mm = view.mismatch64(p - look, k);  // bit i = mismatch at p - look + i
+        const u64 mm = tile_mismatch64(p - look, k);  // bit i = mismatch at p - look + i
         if ((mm >> look) & 0xFFull) continue;         // the group [p, p+8) does not match throughout
         const u64 lead = mm & ((1ull << look) - 1ull);
         u64 a;
@@ -198,86 +271,361 @@ __device__ __forceinline__ void verify_stream(const prf_window_view &view, const
         }
         if (a < tc.tile_base) continue;  // owned by the tile that holds the start
         const u64 seen = (mm >> look) >> 8;  // bit i = mismatch at p + 8 + i, known for i < 56 - look
-        const u64 b = seen ? p + 8 + (u64)__builtin_ctzll(seen) : run_end(view, p + (64 - look), k);
+        const u64 b = seen ? p + 8 + (u64)__builtin_ctzll(seen) : run_end(p + (64 - look), k);
         if ((long long)(b - a) < M) continue;
-        if (!prf_vmotif_is_repeat(view, a, k)) emit_row(tc, to_lds, a, b, k);
+        if (!motif_is_repeat(a, k)) emit_row(tc, to_lds, a, b, k);
     }
 }
 
-// Candidate records -> rows.  only_list >= 0: the records [0, n) of that wave's list, taken by lanes
-// first, first+stride, ... (a wave emptying its own full list in the middle of the scan).  only_list < 0:
-// the records of all lists, as one index space [0, n) (the cooperative pass at the end of the tile).
-__device__ __forceinline__ void verify_records_impl(prf_lds_cu64 *recs, int only_list, u32 n, u32 first, u32 stride, bool to_lds) {
-    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
-    const prf_window_view view = make_view(tc);
-    const u32 *rec_cnt = smem_rec_cnt();
-    const u32 c0 = rec_cnt[0], c1 = c0 + rec_cnt[1], c2 = c1 + rec_cnt[2];
-    for (u32 idx = first; idx < n; idx += stride) {
-        u32 slot_idx;
-        if (only_list >= 0) slot_idx = (u32)only_list * REC_PER_WAVE + idx;
-        else if (idx < c0) slot_idx = idx;
-        else if (idx < c1) slot_idx = REC_PER_WAVE + (idx - c0);
-        else if (idx < c2) slot_idx = 2 * REC_PER_WAVE + (idx - c1);
-        else slot_idx = 3 * REC_PER_WAVE + (idx - c2);
-        const u64 rec = recs[slot_idx];
+// ---- lean verification for the common case: a candidate of a clean tile whose looks stay inside the LDS window ----
+// Window positions: bit 0 of the window = 64 positions before the tile; the window holds H and L (the not-ACGT plane is known
+// to be zero there).  32-bit words, v_alignbit funnel shifts.
+constexpr u32 WIN_POS = (u32)LW * 64u;  // positions in the window
+
+__device__ __forceinline__ u32 look32(prf_lds_cu32 *plane, u32 q) {
+    const u32 w = q >> 5;
+    return __builtin_amdgcn_alignbit(plane[w + 1], plane[w], q & 31u);
+}
+__device__ __forceinline__ u64 look64(prf_lds_cu32 *plane, u32 q) {
+    const u32 w = q >> 5, sft = q & 31u;
+    const u32 w0 = plane[w], w1 = plane[w + 1], w2 = plane[w + 2];
+    return (u64)__builtin_amdgcn_alignbit(w1, w0, sft) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sft) << 32);
+}
+// mismatch bits of window positions q .. q+31 / q+63 against q+k ..; the caller guarantees q + k + 96 <= WIN_POS
+__device__ __forceinline__ u32 win_mismatch32(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 q, u32 k) {
+    return (look32(h, q) ^ look32(h, q + k)) | (look32(l, q) ^ look32(l, q + k));
+}
+__device__ __forceinline__ u64 win_mismatch64(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 q, u32 k) {
+    return (look64(h, q) ^ look64(h, q + k)) | (look64(l, q) ^ look64(l, q + k));
+}
+
+struct WinCtx {
+    prf_lds_cu32 *h, *l, *cof;
+    u64 win0;  // global position of window bit 0
+    u32 min_repeats, min_span;
+};
+
+__device__ __forceinline__ u32 min_matches32(u32 k, u32 min_repeats, u32 min_span) {
+    const u32 a = (min_repeats - 1u) * k, b = min_span > k ? min_span - k : 0u;
+    return a > b ? a : b;
+}
+
+// end of the run at motif size k that matches up to window position `from` (global position returned); leaves the
+// window -> the general routine
+__device__ __forceinline__ u64 win_run_end(const WinCtx &wc, u32 from, u32 k) {
+    for (;;) {
+        if (from + k + 96u > WIN_POS) return run_end(wc.win0 + from, k);
+        const u64 m2 = win_mismatch64(wc.h, wc.l, from, k);
+        if (m2) return wc.win0 + from + (u64)__builtin_ctzll(m2);
+        from += 64u;
+    }
+}
+
+// motif [a, a+k) at window position a: a power of a shorter word?  (see motif_is_repeat)
+__device__ __forceinline__ bool win_motif_is_repeat(const WinCtx &wc, u32 a, u32 k) {
+    if (a + 2u * k + 96u > WIN_POS) return motif_is_repeat(wc.win0 + a, k);
+    for (u32 cf = wc.cof[k]; cf; cf >>= 8) {
+        const u32 d = cf & 255u, need = k - d;
+        bool has = true;
+        for (u32 off = 0; off < need; off += 32) {
+            u32 mm = win_mismatch32(wc.h, wc.l, a + off, d);
+            const u32 left = need - off;
+            if (left < 32) mm &= (1u << left) - 1u;
+            if (mm) {
+                has = false;
+                break;
+            }
+        }
+        if (has) return true;
+    }
+    return false;
+}
+
+// funnel shift right of the 128-bit value hi:lo by s in [1, 63]
+__device__ __forceinline__ u64 shr128(u64 lo, u64 hi, u32 sft) { return (lo >> sft) | (hi << (64u - sft)); }
+
+// cofactors k/p of the distinct primes p | k for k <= 15, two 4-bit fields per byte (see CofTable): no table look for the exact tasks
+__device__ __forceinline__ u32 small_cof(u32 k) {
+    const u64 t = k < 8u ? 0x0123010201010000ull : 0x0027014601250304ull;
+    return (u32)(t >> (8u * (k & 7u))) & 255u;
+}
+
+// One (stream, exact task) flag of a clean tile: stream (lane rl, bit `bit`), motif size k.  128 positions of both planes
+// from the position in front of the stream are read; the mismatch word, the run starts, the run ends and the periods of the
+// primitive-motif test are funnel shifts of those registers.
+__device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx &wc, u32 rl, u32 bit, u32 k) {
+    const u32 q = 64u + (bit * 64u + rl) * T;  // window position of the stream's first position
+    const u32 w = (q - 1u) >> 5, sft = (q - 1u) & 31u;
+    const u32 a0 = wc.h[w], a1 = wc.h[w + 1], a2 = wc.h[w + 2], a3 = wc.h[w + 3], a4 = wc.h[w + 4];
+    const u32 b0 = wc.l[w], b1 = wc.l[w + 1], b2 = wc.l[w + 2], b3 = wc.l[w + 3], b4 = wc.l[w + 4];
+    // bit i = window position q - 1 + i
+    const u64 hlo = (u64)__builtin_amdgcn_alignbit(a1, a0, sft) | ((u64)__builtin_amdgcn_alignbit(a2, a1, sft) << 32);
+    const u64 hhi = (u64)__builtin_amdgcn_alignbit(a3, a2, sft) | ((u64)__builtin_amdgcn_alignbit(a4, a3, sft) << 32);
+    const u64 llo = (u64)__builtin_amdgcn_alignbit(b1, b0, sft) | ((u64)__builtin_amdgcn_alignbit(b2, b1, sft) << 32);
+    const u64 lhi = (u64)__builtin_amdgcn_alignbit(b3, b2, sft) | ((u64)__builtin_amdgcn_alignbit(b4, b3, sft) << 32);
+    const u32 M = min_matches32(k, wc.min_repeats, wc.min_span);
+    const u64 m = (hlo ^ shr128(hlo, hhi, k)) | (llo ^ shr128(llo, lhi, k));  // bit i = mismatch at window position q - 1 + i
+    u64 r = ~m;  // -> bit i: positions i .. i+M-1 all match (M <= 14: three doublings and a rest)
+    if (M >= 2) r &= r >> 1;
+    if (M >= 4) r &= r >> 2;
+    if (M >= 8) r &= r >> 4;
+    {
+        const u32 len = M >= 8 ? 8u : (M >= 4 ? 4u : (M >= 2 ? 2u : 1u));
+        r &= r >> (M - len);
+    }
+    u64 st = r & (m << 1) & 0x1FFFFFFFEull;  // starts at bits 1 .. 32 = the stream's own positions
+    const u32 cof_k = small_cof(k);
+    while (st) {
+        const u32 i = (u32)__builtin_ctzll(st);
+        st &= st - 1;
+        // primitive motif: no period k/p for a prime p | k (k - d <= 13 positions from the start on)
+        bool rep = false;
+        for (u32 cf = cof_k; cf && !rep; cf >>= 4) {
+            const u32 d = cf & 15u;
+            const u64 md = (hlo ^ shr128(hlo, hhi, d)) | (llo ^ shr128(llo, lhi, d));
+            rep = ((md >> i) & ((1ull << (k - d)) - 1ull)) == 0;
+        }
+        if (rep) continue;
+        const u32 a = q - 1u + i;
+        const u64 after = m >> i;  // bit j = mismatch at a + j, known for j < 64 - i
+        const u64 b = after ? wc.win0 + a + (u64)__builtin_ctzll(after) : win_run_end(wc, a + (64u - i), k);
+        emit_row(tc, true, wc.win0 + a, b, k);
+    }
+}
+
+// group-task record, one flagged stream at window position q, every S-th aligned group of 8 examined: the examined
+// all-match groups that are the first of their run, if the run starts inside the tile.
+// The cheap part (which of the stream's groups qualify) is a loop of its own; the expensive part (run end, length,
+// primitive motif, row) then runs once per qualifying group -- almost always once per stream -- instead of once per group
+// index at which ANY lane of the wave has something.
+__device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx &wc, u32 q, u32 k, u32 S) {
+    const u32 M = min_matches32(k, wc.min_repeats, wc.min_span);
+    const u32 back = 8u * S;
+    const u64 m = win_mismatch64(wc.h, wc.l, q - 32u, k);  // bit i = mismatch at window position q - 32 + i
+    const u32 cof_k = wc.cof[k];
+    u32 leaders = 0;  // bit j: group j of the stream is all-match, the first examined one of its run, and the run starts in the tile
+    u32 nbs = 0;      // 5 bits per group: matches directly before it
+    for (u32 j = 0; j < 4u; j += S) {
+        const u32 gb = 32u + 8u * j;  // bit of the group's first position
+        const u64 lead = m << (64u - gb);  // bit 63 = the position directly before the group
+        const u32 nb = lead ? (u32)__builtin_clzll(lead) : 64u;  // matches directly before it (>= 32 seen)
+        const bool ok = ((m >> gb) & 0xFFull) == 0 && nb < back && q - 32u + gb - nb >= 64u;
+        leaders |= (ok ? 1u : 0u) << j;
+        nbs |= (nb & 31u) << (5u * j);
+    }
+    while (leaders) {
+        const u32 j = (u32)__builtin_ctz(leaders);
+        leaders &= leaders - 1;
+        const u32 gb = 32u + 8u * j, nb = (nbs >> (5u * j)) & 31u;
+        const u32 a = q - 32u + gb - nb;
+        // One batch of looks, issued together (one LDS round trip): the first 32 positions of the period test of up to three
+        // cofactors, and the 64 positions behind the first look for the run's end.  Primitive motif first: most group
+        // candidates are echoes of a short motif.
+        if (a + 2u * k + 96u > WIN_POS) {
+            if (motif_is_repeat(wc.win0 + a, k)) continue;
+        } else {
+            const u32 d1 = cof_k & 255u, d2 = (cof_k >> 8) & 255u, d3 = (cof_k >> 16) & 255u;
+            const u32 mm1 = win_mismatch32(wc.h, wc.l, a, d1 ? d1 : 1u);
+            const u32 mm2 = win_mismatch32(wc.h, wc.l, a, d2 ? d2 : 1u);
+            const u32 mm3 = win_mismatch32(wc.h, wc.l, a, d3 ? d3 : 1u);
+            bool rep = false;
+            for (u32 ci = 0; ci < 4u && !rep; ci++) {
+                const u32 d = (cof_k >> (8u * ci)) & 255u;
+                if (d == 0) break;
+                const u32 need = k - d;
+                u32 mm = ci == 0 ? mm1 : (ci == 1 ? mm2 : (ci == 2 ? mm3 : win_mismatch32(wc.h, wc.l, a, d)));
+                if (need < 32) mm &= (1u << need) - 1u;
+                rep = mm == 0;
+                for (u32 off = 32; off < need && rep; off += 32) {
+                    u32 m2 = win_mismatch32(wc.h, wc.l, a + off, d);
+                    const u32 left = need - off;
+                    if (left < 32) m2 &= (1u << left) - 1u;
+                    rep = m2 == 0;
+                }
+            }
+            if (rep) continue;
+        }
+        const u64 seen = gb + 8u < 64u ? m >> (gb + 8u) : 0ull;  // bit i = mismatch at group end + i
+        u64 b;
+        if (seen) {
+            b = wc.win0 + (q - 32u + gb + 8u) + (u64)__builtin_ctzll(seen);
+        } else {
+            const u64 m2 = win_mismatch64(wc.h, wc.l, q + 32u, k);  // (q + 32 + k + 96 <= WIN_POS for every stream of the tile)
+            b = m2 ? wc.win0 + (q + 32u) + (u64)__builtin_ctzll(m2) : win_run_end(wc, q + 96u, k);
+        }
+        if (b - (wc.win0 + a) < (u64)M) continue;
+        emit_row(tc, true, wc.win0 + a, b, k);
+    }
+}
+
+// Boundary pass.  A group task's run is found at the FIRST examined all-match group it contains.  For a run that starts
+// in the last 8S-1 positions of this tile that group lies in the next tile, whose workgroup drops the run because it does
+// not start there; this tile reports it: per motif size one look at the 32 positions in front of the
+// tile's end.  c = matches directly in front of the end: 1 <= c < 8S <=> such a run exists and starts at end - c.
+__device__ __forceinline__ void boundary_item(const TileCtx &tc, const WinCtx &wc, bool fast, u32 k, u32 S) {
+    const u64 tile_end = tc.tile_base + PRF_TILE;
+    const u32 back = 8u * S;
+    const u64 mm = fast ? win_mismatch64(wc.h, wc.l, 64u + PRF_TILE - 32u, k) : tile_mismatch64(tile_end - 32, k);
+    const u32 lo = (u32)mm;  // bit i = mismatch at tile_end - 32 + i
+    const u32 c = lo ? (u32)__builtin_clz(lo) : 32u;
+    if (c == 0 || c >= back) return;
+    const u64 a = tile_end - c;
+    const u64 hi = mm >> 32;  // bit i = mismatch at tile_end + i
+    const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : (fast ? win_run_end(wc, 64u + PRF_TILE + 32u, k) : run_end(tile_end + 32, k));
+    if (b - a < (u64)min_matches32(k, tc.min_repeats, tc.min_span)) return;
+    if (!(fast ? win_motif_is_repeat(wc, 64u + PRF_TILE - c, k) : motif_is_repeat(a, k))) emit_row(tc, true, a, b, k);
+}
+
+__device__ __forceinline__ prf_lds_u32 *smem_rec_cnt() { return (prf_lds_u32 *)(prf_smem + 128); }   // [MAX_WAVES]: group-task records
+
+// A wave emptying its own full list in the middle of the scan: rare, and called from inside the tasks, so not inlined.
+// General routine only; its rows go straight to the slab (the LDS row list lies where the image still is).
+__device__ __noinline__ void flush_records(prf_lds_cu64 *recs, int wave, u32 n, u32 lane) {
+    const u64 tile_base = reinterpret_cast<const TileCtx *>(prf_smem)->tile_base;
+    for (u32 idx = lane; idx < n; idx += 64u) {
+        const u64 rec = recs[(u32)wave * REC_PER_WAVE + idx];
         const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
         u32 word = (u32)(rec >> 17);
         while (word) {
             const u32 bit = (u32)__builtin_ctz(word);
             word &= word - 1;
-            verify_stream(view, tc, tc.tile_base + (u64)(bit * 64u + rl) * T, k, sc, to_lds);
+            verify_stream(tile_base + (u64)(bit * 64u + rl) * T, k, sc, false);
         }
     }
 }
 
-// A wave emptying its own full list in the middle of the scan: rare, and called from inside the tasks, so not inlined
-// (a function call: the callee saves the registers it uses to scratch memory).  Its rows go straight to the slab.
-__device__ __noinline__ void flush_records(prf_lds_cu64 *recs, int wave, u32 n, u32 lane) {
-    verify_records_impl(recs, wave, n, lane, 64u, false);
-}
-
-// Boundary pass.  A group task's run is found at the FIRST examined all-match group it contains.  For a run that starts
-// in the last 8S-1 positions of this tile that group lies in the next tile, whose workgroup drops the run because it does
-// not start there (verify_stream); this tile reports it: per motif size one look at the 32 positions in front of the
-// tile's end.  c = matches directly in front of the end: 1 <= c < 8S <=> such a run exists and starts at end - c.
-__device__ __forceinline__ void boundary_pass(const prf_vplan &plan, u32 first, u32 stride) {
+// Candidates -> rows, all waves together at the end of the tile.
+//  * exact tasks left one word per (task, lane) in LDS: thread (lane, quarter) takes the streams of its lane whose bit lies
+//    in its quarter of the word and that any task flagged, one stream at a time, all flagging motif sizes at once;
+//  * group-task records and the boundary items are taken by the lanes from the last thread down.
+// Returns the number of (stream, exact task) flags this thread looked at (statistics).
+__device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bitems, u32 n_bitems, u32 tid, u64 *dbg) {
+#ifdef PRF_STAMPS
+#define PRF_VSTAMP(i) do { if (dbg && (tid & 63u) == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PRF_VSTAMP(i) do { } while (0)
+#endif
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
-    const prf_window_view view = make_view(tc);
-    const u64 tile_end = tc.tile_base + PRF_TILE;
-    for (u32 v = first; v < plan.n_tasks * 8u; v += stride) {
-        const prf_vtask task = plan.tasks[v >> 3];
-        const u32 kk = v & 7u;
-        if (task.kind != 0 || !((task.valid >> kk) & 1u)) continue;
-        const u32 k = (u32)task.k0 + kk;
-        const u32 back = 8u * task.stride;
-        const u64 mm = view.mismatch64(tile_end - 32, k);
-        const u32 lo = (u32)mm;  // bit i = mismatch at tile_end - 32 + i
-        const u32 c = lo ? (u32)__builtin_clz(lo) : 32u;
-        if (c == 0 || c >= back) continue;
-        const u64 a = tile_end - c;
-        const u64 hi = mm >> 32;  // bit i = mismatch at tile_end + i
-        const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : run_end(view, tile_end + 32, k);
-        if ((long long)(b - a) < prf_min_matches(k, tc.min_repeats, tc.min_span)) continue;
-        if (!prf_vmotif_is_repeat(view, a, k)) emit_row(tc, true, a, b, k);
+    const bool fast = tc.has_lin != 0;
+    WinCtx wc;
+    wc.h = (prf_lds_cu32 *)(prf_smem + tc.lin_off);
+    wc.l = wc.h + 2 * LW;
+    wc.cof = (prf_lds_cu32 *)(prf_smem + tc.cof_off);
+    wc.win0 = tc.tile_base - 64;
+    wc.min_repeats = tc.min_repeats;
+    wc.min_span = tc.min_span;
+    // ---- exact tasks: one word per (task, lane) lies in LDS.  Every thread collects the flags of its lane's streams in its
+    // quarter of the words, the flags are dealt to the threads one by one through a list (lies where the image was, behind
+    // the row list): a wave then runs the body about once, not as often as its unluckiest lane has flags.
+    u32 n_flags = 0;
+    if (tc.n_exact) {
+        constexpr u32 MAX_EXACT = SMALL_M - 1;  // motif sizes 1 .. 14 at most
+        constexpr u32 FLAG_CAP_WAVE = 1024;
+        typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
+        prf_lds_u16 *flags = (prf_lds_u16 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 16);  // 4 lists of FLAG_CAP_WAVE
+        prf_lds_u32 *flag_cnt = (prf_lds_u32 *)(prf_smem + 172);                         // [MAX_WAVES]
+        prf_lds_cu32 *hotw = (prf_lds_cu32 *)(prf_smem + tc.hotw_off);
+        const u32 n_exact = tc.n_exact, rl = tid & 63u;
+        u32 hw[MAX_EXACT];
+        static_for<0, (int)MAX_EXACT>([&](auto ec) {  // all reads in flight at once (words past the last task are other data: masked)
+            constexpr u32 e = (u32)decltype(ec)::value;
+            hw[e] = hotw[e * 64u + rl];
+        });
+        // the lane's flags of this quarter as two 64-bit words: bit 8 e + b = stream (lane, 8 quarter + b) flagged by task e
+        const u32 qsh = 8u * (tid >> 6);
+        u64 f0 = 0, f1 = 0;
+        static_for<0, (int)MAX_EXACT>([&](auto ec) {
+            constexpr u32 e = (u32)decltype(ec)::value;
+            const u64 byte = e < n_exact ? (u64)((hw[e] >> qsh) & 0xFFu) : 0ull;
+            if constexpr (e < 8) f0 |= byte << (8 * e);
+            else f1 |= byte << (8 * (e - 8));
+        });
+        n_flags = (u32)__builtin_popcountll(f0) + (u32)__builtin_popcountll(f1);
+        // per-wave lists, ballot-compacted: wave-uniform loops, no atomics (the trip count is the largest number of flags any
+        // lane of the wave has in its quarter)
+        const u32 wv = tid >> 6;
+        prf_lds_u16 *mylist = flags + wv * FLAG_CAP_WAVE;
+        u32 cnt = 0;  // wave-uniform
+        for (int half = 0; half < 2; half++) {
+            u64 f = half ? f1 : f0;
+            for (;;) {
+                const u64 bal = __builtin_amdgcn_ballot_w64(f != 0);
+                if (bal == 0) break;
+                if (f) {
+                    const u32 x = (u32)__builtin_ctzll(f);
+                    f &= f - 1;
+                    const u32 at = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                    if (at < FLAG_CAP_WAVE) mylist[at] = (unsigned short)(rl | (((x & 7u) + qsh) << 6) | (((x >> 3) + 8u * (u32)half) << 11));
+                }
+                cnt += (u32)__builtin_popcountll(bal);
+            }
+        }
+        if (rl == 0) flag_cnt[wv] = cnt;
+        PRF_VSTAMP(12);
+        __syncthreads();
+        PRF_VSTAMP(13);
+        const u32 e0 = flag_cnt[0], e1 = e0 + flag_cnt[1], e2 = e1 + flag_cnt[2], total = e2 + flag_cnt[3];
+        if (flag_cnt[0] <= FLAG_CAP_WAVE && flag_cnt[1] <= FLAG_CAP_WAVE && flag_cnt[2] <= FLAG_CAP_WAVE && flag_cnt[3] <= FLAG_CAP_WAVE) {
+            for (u32 idx = tid; idx < total; idx += (u32)NTH) {
+                const u32 slot_idx = idx < e0 ? idx : (idx < e1 ? FLAG_CAP_WAVE + (idx - e0) : (idx < e2 ? 2 * FLAG_CAP_WAVE + (idx - e1) : 3 * FLAG_CAP_WAVE + (idx - e2)));
+                const u32 f = flags[slot_idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
+                // (the tile's first stream looks at positions in front of the tile, where N is possible: general routine)
+                if (fast && (frl | fbit)) win_verify_flag(tc, wc, frl, fbit, k);
+                else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u, true);
+            }
+        } else {  // a tile of long runs: every thread takes its own flags
+            for (int half = 0; half < 2; half++) {
+                u64 f = half ? f1 : f0;
+                while (f) {
+                    const u32 x = (u32)__builtin_ctzll(f);
+                    f &= f - 1;
+                    verify_stream(tc.tile_base + (u64)(((x & 7u) + qsh) * 64u + rl) * T, tc.k_exact0 + (x >> 3) + 8u * (u32)half, 0u, true);
+                }
+            }
+        }
     }
+    PRF_VSTAMP(14);
+    {
+        prf_lds_u32 *cg = smem_rec_cnt();
+        const u32 c0 = cg[0], c1 = c0 + cg[1], c2 = c1 + cg[2], n = c2 + cg[3];
+        for (u32 idx = (u32)NTH - 1u - tid; idx < n + n_bitems; idx += (u32)NTH) {
+            if (idx < n) {
+                const u32 slot_idx = idx < c0 ? idx : (idx < c1 ? REC_PER_WAVE + (idx - c0) : (idx < c2 ? 2 * REC_PER_WAVE + (idx - c1) : 3 * REC_PER_WAVE + (idx - c2)));
+                const u64 rec = recs[slot_idx];
+                const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
+                u32 word = (u32)(rec >> 17);
+                while (word) {
+                    const u32 bit = (u32)__builtin_ctz(word);
+                    word &= word - 1;
+                    const u32 sq = (bit * 64u + rl) * T;
+                    if (fast && sq >= 32u) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
+                    else verify_stream(tc.tile_base + sq, k, sc, true);
+                }
+            } else {  // boundary item
+                const u32 it = bitems[idx - n];
+                boundary_item(tc, wc, fast, it & 0xFFFFu, it >> 16);
+            }
+        }
+    }
+    return n_flags;
 }
 
-// One 32-bit word per lane (bit b = stream b*64 + lane is flagged for motif size k) -> records of the lanes with a
-// non-zero word.  Every lane of the wave calls this together.
+// Group tasks: one 32-bit word per lane (bit b = stream b*64 + lane is flagged for motif size k) -> records of the lanes
+// with a non-zero word.  Every lane of the wave calls this together.
 struct Emit {
-    u64 *recs;           // this wave's list in LDS, REC_PER_WAVE records
-    u64 *all_recs;       // all lists
+    prf_lds_u64 *recs;       // this wave's list in LDS, REC_PER_WAVE records
+    prf_lds_cu64 *all_recs;  // all lists
     int wave;
     int lane;
-    u32 cnt;             // records in it (wave-uniform)
-    u32 flushed;         // records verified in early flushes (wave-uniform)
+    u32 cnt;                 // records in it (wave-uniform)
+    u32 flushed;             // records verified in early flushes (wave-uniform)
 
     __device__ __forceinline__ void push_word(u32 word, u32 k, u32 sc) {
         const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
         if (bal == 0) return;
         const u32 n = (u32)__builtin_popcountll(bal);
         if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
-            flush_records((prf_lds_cu64 *)all_recs, wave, cnt, (u32)lane);
+            flush_records(all_recs, wave, cnt, (u32)lane);
             flushed += cnt;
             cnt = 0;
         }
@@ -302,7 +650,7 @@ __device__ __forceinline__ u32 nor_and(u32 a, u32 b, u32 c) { return bitop3<(~(T
 // a | b | c
 __device__ __forceinline__ u32 or3(u32 a, u32 b, u32 c) { return bitop3<(TA | TB | TC) & 0xFF>(a, b, c); }
 
-__device__ __forceinline__ void unpack4(u32 *dst, const uint4 v) {
+__device__ __forceinline__ void unpack4(u32 *dst, const prf_u32x4 v) {
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
 }
 
@@ -318,7 +666,7 @@ __device__ __forceinline__ P *slot_of(P *lane_base, int gg) {
 // Slot g (compile-time) after a run-time first slot gg0 whose address `first` = slot_of(lane_base, gg0) and
 // a = gg0 & 7 are computed once per block: the stream wraps into the next virtual lane at most once within a block.
 template <int NC, int G>
-__device__ __forceinline__ const uint4 *slot_after(const uint4 *first, int a) {
+__device__ __forceinline__ prf_lds_cu4 *slot_after(prf_lds_cu4 *first, int a) {
     return first + G * NC + (a + G >= 8 ? 1 - 8 * NC : 0);
 }
 
@@ -327,10 +675,10 @@ __device__ __forceinline__ const uint4 *slot_after(const uint4 *first, int a) {
 // (stride 2 / 4) every examined all-match group counts.  The per-size words are OR-ed over the blocks and leave as records
 // at the end of the task.
 template <bool HASX, int NC, bool S1>
-__device__ __forceinline__ void group_task(const uint4 *vimg, const uint4 *ximg, int lane, u32 k0, u32 valid, u32 stride, Emit &em) {
+__device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, u32 k0, u32 valid, u32 stride, Emit &em) {
     constexpr int PS = RG * NC;  // slots per plane
-    const uint4 *lane_base = vimg + lane;
-    const uint4 *xlane_base = ximg + lane;
+    prf_lds_cu4 *lane_base = vimg + lane;
+    prf_lds_cu4 *xlane_base = ximg + lane;
     u32 prev[8], acc[8];
     static_for<0, 8>([&](auto ic) {
         prev[decltype(ic)::value] = ~0u;  // first group of a stream: counts, verification decides
@@ -343,8 +691,8 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, const uint4 *ximg,
         const int g0 = 2 * tb + (int)(k0 >> 2);
         const int wa = g0 & 7;
         {
-            const uint4 *pa = lane_base + 2 * tb * NC;
-            const uint4 *pw0 = slot_of<NC>(lane_base, g0);
+            prf_lds_cu4 *pa = lane_base + 2 * tb * NC;
+            prf_lds_cu4 *pw0 = slot_of<NC>(lane_base, g0);
             static_for<0, 2>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 unpack4(&a[p][0], pa[p * PS]);
@@ -352,7 +700,7 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, const uint4 *ximg,
             });
             static_for<0, 4>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                const uint4 *pw = slot_after<NC, g>(pw0, wa);
+                prf_lds_cu4 *pw = slot_after<NC, g>(pw0, wa);
                 static_for<0, 2>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     unpack4(&w[p][4 * g], pw[p * PS]);
@@ -360,8 +708,8 @@ __device__ __forceinline__ void group_task(const uint4 *vimg, const uint4 *ximg,
             });
         }
         if constexpr (HASX) {
-            const uint4 *pa = xlane_base + 2 * tb * NC;
-            const uint4 *pw0 = slot_of<NC>(xlane_base, g0);
+            prf_lds_cu4 *pa = xlane_base + 2 * tb * NC;
+            prf_lds_cu4 *pw0 = slot_of<NC>(xlane_base, g0);
             unpack4(&a[2][0], pa[0]);
             unpack4(&a[2][4], pa[NC]);
             static_for<0, 4>([&](auto gc) {
@@ -503,16 +851,20 @@ __device__ __forceinline__ u32 exact_any(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, i
 }
 
 template <bool HASX, int NC>
-__device__ __forceinline__ void run_tasks(const uint4 *vimg, const uint4 *ximg, const prf_vplan &plan, int wave, int lane, Emit &em) {
+__device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, prf_lds_u32 *hotw, const prf_vplan &plan, int wave, int lane,
+                                          Emit &em, u64 *dbg) {
     const u32 t_end = plan.wave_begin[wave + 1];
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
         const prf_vtask task = plan.tasks[ti];
+#ifdef PRF_STAMPS
+        if (dbg && lane == 0 && ti - plan.wave_begin[wave] < 8u) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
+#endif
         if (task.kind == 0) {
             if (task.stride == 1) group_task<HASX, NC, true>(vimg, ximg, lane, task.k0, task.valid, 1u, em);
             else group_task<HASX, NC, false>(vimg, ximg, lane, task.k0, task.valid, task.stride, em);
         } else {
-            const u32 hot = exact_any<NC>((prf_lds_cu4 *)vimg, (prf_lds_cu4 *)ximg, lane, HASX, task.k0, task.kind);
-            em.push_word(hot, task.k0, 0u);
+            // the lane's word for this task goes to LDS as it is: no ballot, no list (verify_all)
+            hotw[(u32)task.item0 * 64u + (u32)lane] = exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind);
         }
     }
 }
@@ -522,12 +874,14 @@ __device__ __forceinline__ void run_tasks(const uint4 *vimg, const uint4 *ximg, 
 template <int NC>
 __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr int nc = NC;
-    uint4 *vimg = reinterpret_cast<uint4 *>(prf_smem + SMEM_HDR);
-    const u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)2 * RG * nc * sizeof(uint4));
-    u64 *lin = reinterpret_cast<u64 *>(prf_smem + lin_off);
-    uint4 *ximg = reinterpret_cast<uint4 *>(prf_smem + lin_off);  // tiles with N in reach: instead of the window
-    u64 *recs = lin + 2 * LW;
-    u32 *rec_cnt = smem_rec_cnt();
+    prf_lds_u4 *vimg = (prf_lds_u4 *)(prf_smem + SMEM_HDR);
+    constexpr u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)2 * RG * nc * sizeof(prf_u32x4));
+    prf_lds_u64 *lin = (prf_lds_u64 *)(prf_smem + lin_off);
+    prf_lds_u4 *ximg = (prf_lds_u4 *)(prf_smem + lin_off);  // tiles with N in reach: instead of the window
+    prf_lds_u64 *recs = lin + 2 * LW;
+    prf_lds_u32 *hotw = (prf_lds_u32 *)(recs + MAX_WAVES * REC_PER_WAVE);  // exact tasks: [task][lane] stream words, then 16 x (k | M << 16)
+    prf_lds_u32 *bitems = hotw + g.plan.n_exact * 64u + 16u;                // boundary items, plan.n_group_k of them
+    prf_lds_u32 *hdr_cnt = (prf_lds_u32 *)(prf_smem + 128);
 
     const int tid = (int)threadIdx.x;
     const u32 slot = blockIdx.x;
@@ -540,12 +894,13 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const int lane = tid & 63;
     constexpr int extra = NC - 64;
 
+    PRF_STAMP(0);
     // ---- 1. stage ----
     // All global loads of a thread are issued back to back before the first LDS store, so the workgroup pays
     // one memory round trip (a load -> store loop pays one per iteration: measured 7 k cycles per tile).
     {
-        const uint4 *ph = reinterpret_cast<const uint4 *>(g.VH), *pL = reinterpret_cast<const uint4 *>(g.VL),
-                    *px = reinterpret_cast<const uint4 *>(g.VX);
+        const prf_u32x4 *ph = reinterpret_cast<const prf_u32x4 *>(g.VH), *pL = reinterpret_cast<const prf_u32x4 *>(g.VL),
+                        *px = reinterpret_cast<const prf_u32x4 *>(g.VX);
         const int np = hasx ? 3 : 2;
         const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;  // the planes have readable padding in front
         // H and L bit-sliced planes = 4 slots per thread, X plane (tiles with N) 2 more;
@@ -553,11 +908,11 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         constexpr int NLF = (2 * LW) / NTH;          // full rounds of linear words
         constexpr int NLT = (2 * LW) - NLF * NTH;    // tail
         const int rg = tid >> 6, l = tid & 63;       // slot (rg + 4*j, l) of plane p
-        const uint4 *th = ph + (tile * RG + rg) * 64 + l, *tl = pL + (tile * RG + rg) * 64 + l;
-        const uint4 vh0 = th[0], vh1 = th[4 * 64], vl0 = tl[0], vl1 = tl[4 * 64];
-        uint4 vx0 = make_uint4(0, 0, 0, 0), vx1 = vx0;
+        const prf_u32x4 *th = ph + (tile * RG + rg) * 64 + l, *tl = pL + (tile * RG + rg) * 64 + l;
+        const prf_u32x4 vh0 = th[0], vh1 = th[4 * 64], vl0 = tl[0], vl1 = tl[4 * 64];
+        prf_u32x4 vx0 = {0, 0, 0, 0}, vx1 = vx0;
         if (hasx) {
-            const uint4 *tx = px + (tile * RG + rg) * 64 + l;
+            const prf_u32x4 *tx = px + (tile * RG + rg) * 64 + l;
             vx0 = tx[0];
             vx1 = tx[4 * 64];
         }
@@ -576,20 +931,31 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         // tile with N in reach) are 384 slots: two rounds of the 256 threads cover every instantiated width.
         constexpr int NXR = (3 * RG * extra + NTH - 1) / NTH;
         static_assert(3 * RG * extra <= NXR * NTH, "virtual-lane staging rounds do not cover the image width");
-        uint4 ev[NXR], en[NXR];
+        prf_u32x4 ev[NXR], en[NXR];
         const int n_extra = np * RG * extra;
         static_for<0, NXR>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             const int s = tid + r * NTH;
-            ev[r] = make_uint4(0, 0, 0, 0);
+            ev[r] = prf_u32x4{0, 0, 0, 0};
             en[r] = ev[r];
             if (s < n_extra) {
                 const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
-                const uint4 *src = p == 0 ? ph : (p == 1 ? pL : px);
-                ev[r] = src[(tile * RG + erg) * 64 + el];
-                en[r] = src[((tile + 1) * RG + erg) * 64 + el];
+                const u64 i0 = (tile * RG + erg) * 64 + el, i1 = ((tile + 1) * RG + erg) * 64 + el;
+                if (p == 0) {  // (three branches, not a pointer picked from a table: that table would live in scratch memory)
+                    ev[r] = ph[i0];
+                    en[r] = ph[i1];
+                } else if (p == 1) {
+                    ev[r] = pL[i0];
+                    en[r] = pL[i1];
+                } else {
+                    ev[r] = px[i0];
+                    en[r] = px[i1];
+                }
             }
         });
+        // the tile's contig (contigs start on tile boundaries, so every run that starts in this tile lies in it): one load
+        uint4 info = make_uint4(0, 0, 0, 0);
+        if (tid == 0) info = g.tile_info[tile];
         vimg[(0 * RG + rg) * nc + l] = vh0;
         vimg[(0 * RG + rg + 4) * nc + l] = vh1;
         vimg[(1 * RG + rg) * nc + l] = vl0;
@@ -609,15 +975,25 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             const int s = tid + r * NTH;
             if (s < n_extra) {
                 const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
-                uint4 v;
-                v.x = (ev[r].x >> 1) | (en[r].x << 31);
-                v.y = (ev[r].y >> 1) | (en[r].y << 31);
-                v.z = (ev[r].z >> 1) | (en[r].z << 31);
-                v.w = (ev[r].w >> 1) | (en[r].w << 31);
-                (p == 2 ? ximg : vimg + (size_t)p * RG * nc)[erg * nc + 64 + el] = v;
+                const prf_u32x4 v = (ev[r] >> 1) | (en[r] << 31);
+                const int dst = erg * nc + 64 + el;
+                if (p == 2) ximg[dst] = v;
+                else vimg[p * RG * nc + dst] = v;
             }
         });
-        if (tid < 2 * MAX_WAVES + 2) rec_cnt[tid] = 0;  // list lengths, flushed counts, row count, direct-row count
+        if (tid < 2 * MAX_WAVES + 3) hdr_cnt[tid] = 0;  // list lengths, row count, direct-row count, flushed records
+        // boundary items: (motif size, examined-group stride) of every motif size a group task scans; (k, M) of the exact tasks
+        for (u32 v = (u32)tid; v < 8u * g.plan.n_tasks; v += (u32)NTH) {
+            const prf_vtask task = g.plan.tasks[v >> 3];
+            const u32 kk = v & 7u;
+            if (task.kind == 0 && ((task.valid >> kk) & 1u))
+                bitems[(u32)task.item0 + (u32)__builtin_popcount((u32)task.valid & ((1u << kk) - 1u))] = ((u32)task.k0 + kk) | ((u32)task.stride << 16);
+            if (task.kind != 0 && kk == 0) hotw[g.plan.n_exact * 64u + task.item0] = (u32)task.k0 | ((u32)task.kind << 16);
+        }
+        {
+            prf_lds_u32 *cof_lds = bitems + g.plan.n_group_k;
+            for (int i = tid; i < (int)g.plan.cof_words; i += NTH) cof_lds[i] = prf_cof_table.v[i];
+        }
         if (tid == 0) {
             TileCtx tc;
             tc.w0 = tile * PRF_TILE_WORDS - LIN_PRE;
@@ -625,49 +1001,60 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
             tc.H = g.H; tc.L = g.L; tc.X = g.X;
             tc.slab = g.slabs + (u64)slot * g.slab_cap;
-            // contigs start on tile boundaries, so every run that starts in this tile lies in the tile's contig
-            tc.contig = prf_contig_of(g.contig_base, g.n_contigs, tile * PRF_TILE);
-            tc.contig_base = g.contig_base[tc.contig];
+            tc.contig = info.x;
+            tc.contig_base = (u64)info.z | ((u64)info.w << 32);
             tc.tile_base = tile * PRF_TILE;
             tc.slab_cap = g.slab_cap;
             tc.min_repeats = g.min_repeats;
             tc.min_span = g.min_span;
             tc.lin_off = lin_off;
             tc.has_lin = hasx ? 0u : 1u;
+            tc.hotw_off = lin_off + (u32)(2 * LW * sizeof(u64) + MAX_WAVES * REC_PER_WAVE * sizeof(u64));
+            tc.n_exact = g.plan.n_exact;
+            tc.k_exact0 = g.plan.k_exact0;
+            tc.cof_off = tc.hotw_off + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
             *reinterpret_cast<TileCtx *>(prf_smem) = tc;
         }
     }
+    PRF_STAMP(1);
     __syncthreads();
+    PRF_STAMP(2);
 
     // ---- 2. scan ----
     Emit em;
     em.recs = recs + wave * REC_PER_WAVE;
-    em.all_recs = recs;
+    em.all_recs = (prf_lds_cu64 *)recs;
     em.wave = wave;
     em.lane = lane;
     em.cnt = 0;
     em.flushed = 0;
-    if (hasx) run_tasks<true, NC>(vimg, ximg, g.plan, wave, lane, em);
-    else run_tasks<false, NC>(vimg, ximg, g.plan, wave, lane, em);
+#ifdef PRF_STAMPS
+    u64 *task_dbg = g.dbg ? g.dbg + ((u64)blockIdx.x * MAX_WAVES + wave) * 16 : nullptr;
+#else
+    u64 *task_dbg = nullptr;
+#endif
+    if (hasx) run_tasks<true, NC>((prf_lds_cu4 *)vimg, (prf_lds_cu4 *)ximg, hotw, g.plan, wave, lane, em, task_dbg);
+    else run_tasks<false, NC>((prf_lds_cu4 *)vimg, (prf_lds_cu4 *)ximg, hotw, g.plan, wave, lane, em, task_dbg);
     if (lane == 0) {
-        rec_cnt[wave] = em.cnt;
-        smem_rec_flushed()[wave] = em.flushed;
+        hdr_cnt[wave] = em.cnt;
+        if (em.flushed) atomicAdd((u32 *)(prf_smem + 168), em.flushed);
     }
+    PRF_STAMP(3);
     __syncthreads();  // the image is dead from here on: the row list may lie there
+    PRF_STAMP(4);
 
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's LDS list, or nothing ----
-    u32 total = 0;
-    for (int w = 0; w < MAX_WAVES; w++) total += rec_cnt[w];
-    // (statistics: the candidate-record count goes out now, so that the atomic is long acknowledged when the kernel ends)
-    if (tid == 0) {
-        u32 n_records = total;
-        for (int w = 0; w < MAX_WAVES; w++) n_records += smem_rec_flushed()[w];
-        if (n_records)
-            atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_records);
+    u32 n_flags = verify_all((prf_lds_cu64 *)recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (u32)tid, task_dbg);
+    // statistics: candidates looked at = (stream, exact task) flags + group-task records
+    for (int o = 32; o > 0; o >>= 1) n_flags += __shfl_xor(n_flags, o, 64);
+    if (lane == 0) {
+        if (wave == 0) n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
+        if (n_flags)
+            atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
     }
-    verify_records_impl((prf_lds_cu64 *)recs, -1, total, (u32)tid, (u32)NTH, true);  // inlined: no call, no register saves
-    boundary_pass(g.plan, (u32)tid, (u32)NTH);
+    PRF_STAMP(5);
     __syncthreads();
+    PRF_STAMP(6);
 
     // ---- 4. the tile's rows, sorted by (start, end), into its slab: [rows written directly, unsorted][the LDS list, sorted].
     // Rank of a row = number of rows of the list with a smaller key; keys are distinct ((start, end) pairs never collide
@@ -677,87 +1064,126 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const u32 n_direct = *smem_direct_cnt();
     const u32 n_sorted = n_listed < (u32)ROW_CAP_LDS ? n_listed : (u32)ROW_CAP_LDS;
     const u32 n_rows = n_sorted + n_direct;  // rows beyond the list's capacity were counted in n_direct
-    if ((u32)tid < n_sorted) {
-        const u64 *keys = smem_row_keys();
-        const u64 mine = keys[tid];
+    if (n_sorted) {
+        // P = 256 / n threads per row (a power of two, adjacent lanes): each counts the smaller keys of its share of the
+        // list, the shares are added up across the P lanes
+        const u32 lg = n_sorted > 128u ? 0u : (n_sorted > 64u ? 1u : (n_sorted > 32u ? 2u : (n_sorted > 16u ? 3u : 4u)));
+        const u32 P = 1u << lg, row = (u32)tid >> lg, part = (u32)tid & (P - 1u);
+        prf_lds_u32 *keys = smem_row_keys();
+        const u32 mine = row < n_sorted ? keys[row] : 0u;
         u32 rank = 0;
-        for (u32 j = 0; j < n_sorted; j++) rank += keys[j] < mine ? 1u : 0u;  // same address for every lane: a broadcast read
+        if (row < n_sorted) {
+            // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, four in flight
+            // (reads past the list stay inside the dead image)
+            typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
+            prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)keys;
+            for (u32 c0 = part; 4u * c0 < n_sorted; c0 += 4u * P) {
+                prf_u32x4 v[4];
+#pragma unroll
+                for (u32 j = 0; j < 4u; j++) v[j] = k4[c0 + j * P];
+#pragma unroll
+                for (u32 j = 0; j < 4u; j++) {
+                    const u32 b0 = 4u * (c0 + j * P);
+                    rank += (b0 < n_sorted && v[j].x < mine) ? 1u : 0u;
+                    rank += (b0 + 1u < n_sorted && v[j].y < mine) ? 1u : 0u;
+                    rank += (b0 + 2u < n_sorted && v[j].z < mine) ? 1u : 0u;
+                    rank += (b0 + 3u < n_sorted && v[j].w < mine) ? 1u : 0u;
+                }
+            }
+        }
+        for (u32 o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);  // wave-uniform trip count
         const u32 dst = n_direct + rank;
-        if (dst < tc.slab_cap) {
+        if (row < n_sorted && part == 0 && dst < tc.slab_cap) {
+            const u64 end = smem_row_ends()[row];
             prf_hit_dev h;
-            h.start = tc.tile_base + (mine >> 40) - tc.contig_base;
-            h.end = tc.tile_base + (mine & ((1ull << 40) - 1ull)) - tc.contig_base;
-            h.k = smem_row_ks()[tid];
+            h.start = tc.tile_base + (mine >> 16) - tc.contig_base;
+            h.end = end - tc.contig_base;
+            h.k = smem_row_ks()[row];
             h.contig = tc.contig;
             tc.slab[dst] = h;
         }
     }
     if (tid == 0) {
         g.slab_count[slot] = n_rows;
+        const u32 stored = n_rows < tc.slab_cap ? n_rows : tc.slab_cap;
+        if (stored) {  // rows in front of a gather workgroup's slots: two levels of sums
+            atomicAdd(&g.block_sum[slot / PRF_GATHER_SLOTS], stored);
+            atomicAdd(&g.block_sum[g.super_off + slot / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER)], stored);
+        }
         if (n_rows > tc.slab_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
         if (n_direct) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
     }
+    PRF_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Row gather: the slabs, in launch (= position) order, become ONE compact array.  Workgroup w owns the launch slots
-// [256 w, 256 w + 256): it sums the counts in front of them (the counts are tiny: 4 B per 65536 positions), scans its own,
-// and every wave copies the slabs of its slots.  The workgroup that finishes last hands the counter block to the host
-// (mapped memory, no copy call) and clears the block of the next scan (no memset call).
+// [8 w, 8 w + 8): the rows in front of them are sums the scan kernel has added up (two atomics per tile: per 8 slots and per
+// 512 slots); it scans its own 8 counts and copies its slabs word by word, four loads in flight per thread.  The workgroup
+// that finishes last hands the counter block to the host (mapped memory, no copy call), and clears the sums and the
+// counter block of the next scan (no memset call).
 __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     __shared__ u64 part[4];
-    __shared__ u32 offs[257];
+    __shared__ u32 offs[PRF_GATHER_SLOTS + 1];  // in words (3 per row)
     __shared__ u64 ticket_lds;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 first = blockIdx.x * 256u;
-    // rows in front of this workgroup's slots
+    const u32 first = blockIdx.x * PRF_GATHER_SLOTS;
+    const u32 my_super = blockIdx.x / PRF_GATHER_SUPER;
     u64 before = 0;
-    for (u32 i = tid; i < first; i += 256u) {
-        const u32 c = g.slab_count[i];
-        before += c < g.slab_cap ? c : g.slab_cap;
-    }
+    for (u32 i = tid; i < my_super; i += 256u) before += g.block_sum[g.super_off + i];
+    if (tid < blockIdx.x - my_super * PRF_GATHER_SUPER) before += g.block_sum[my_super * PRF_GATHER_SUPER + tid];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
-    // own counts -> exclusive scan
-    const u32 mine_slot = first + tid;
-    u32 cnt = 0;
-    if (mine_slot < g.n_launch) {
-        const u32 c = g.slab_count[mine_slot];
-        cnt = c < g.slab_cap ? c : g.slab_cap;
+    if (tid < 64u) {  // exclusive scan of the 8 counts (loaded in parallel)
+        u32 c = (tid < PRF_GATHER_SLOTS && first + tid < g.n_launch) ? g.slab_count[first + tid] : 0u;
+        c = 3u * (c < g.slab_cap ? c : g.slab_cap);
+        u32 incl = c;
+        for (int o = 1; o < (int)PRF_GATHER_SLOTS; o <<= 1) {
+            const u32 up = __shfl_up(incl, o, 64);
+            if ((int)tid >= o) incl += up;
+        }
+        if (tid < PRF_GATHER_SLOTS) offs[tid + 1] = incl;
+        if (tid == 0) offs[0] = 0;
     }
-    offs[tid + 1] = cnt;
-    if (tid == 0) offs[0] = 0;
     __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (int i = 1; i <= 256; i++) {
-            run += offs[i];
-            offs[i] = run;
+    const u64 base0 = part[0] + part[1] + part[2] + part[3];  // rows in front of this workgroup's slots
+    const u32 n_words = offs[PRF_GATHER_SLOTS];
+    // rows beyond the capacity stay behind: the host sees the total beyond the capacity, grows the array, rescans
+    const u64 room_rows = base0 < g.rows_cap ? g.rows_cap - base0 : 0;
+    const u64 room_words = 3ull * room_rows;
+    const u32 n_copy = (u64)n_words < room_words ? n_words : (u32)room_words;
+    u64 *dst = reinterpret_cast<u64 *>(g.rows + base0);
+    for (u32 w0 = tid; w0 < n_copy; w0 += 1024u) {
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 w = w0 + 256u * (u32)j;
+            v[j] = 0;
+            if (w < n_copy) {
+                u32 lo = 0;  // the slot whose words hold w: offs[lo] <= w < offs[lo + 1]
+#pragma unroll
+                for (u32 i = 1; i < PRF_GATHER_SLOTS; i++) lo += offs[i] <= w ? 1u : 0u;
+                v[j] = reinterpret_cast<const u64 *>(g.slabs + (u64)(first + lo) * g.slab_cap)[w - offs[lo]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 w = w0 + 256u * (u32)j;
+            if (w < n_copy) dst[w] = v[j];
         }
     }
-    __syncthreads();
-    const u64 base0 = part[0] + part[1] + part[2] + part[3];
-    // copy: wave w takes slots w, w+4, ...; 3 words per row
-    for (u32 s = wave; s < 256u && first + s < g.n_launch; s += 4u) {
-        const u32 n = offs[s + 1] - offs[s];
-        if (n == 0) continue;
-        const u64 dst_row = base0 + offs[s];
-        const u64 *src = reinterpret_cast<const u64 *>(g.slabs + (u64)(first + s) * g.slab_cap);
-        // rows beyond the capacity: the host sees the total beyond the capacity, grows the array, rescans
-        const u64 room = dst_row < g.rows_cap ? g.rows_cap - dst_row : 0;
-        const u32 n_copy = (u64)n < room ? n : (u32)room;
-        u64 *dst = reinterpret_cast<u64 *>(g.rows + dst_row);
-        for (u32 i = lane; i < 3u * n_copy; i += 64u) dst[i] = src[i];
-    }
     // the workgroup of the last slots knows the total
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + offs[256]);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_words / 3u);
     __syncthreads();  // every wave's stores and atomics are issued; the barrier waits for outstanding memory operations
     if (tid == 0) ticket_lds = atomicAdd(&g.counters[PRF_CNT_TICKET], 1ull);
     __syncthreads();
     // ---- the last workgroup to draw a ticket hands the counter block to the host.  The counters are only ever touched
     // by device-scope atomics, performed at the coherence point, and every workgroup's were issued in front of the
-    // barrier that precedes its ticket (s_waitcnt vmcnt(0) before s_barrier), so they precede the last ticket.
+    // barrier that precedes its ticket (s_waitcnt vmcnt(0) before s_barrier), so they precede the last ticket.  Every
+    // other workgroup has read its block sums by then: they are cleared for the next scan.
     if (ticket_lds == (u64)gridDim.x - 1ull) {
+        for (u32 i = tid; i < gridDim.x; i += 256u) g.block_sum[i] = 0;
+        for (u32 i = tid; i <= (gridDim.x - 1u) / PRF_GATHER_SUPER; i += 256u) g.block_sum[g.super_off + i] = 0;
         for (u32 i = tid; i < (u32)PRF_CNT_N; i += 256u) {
             const u64 v = atomicAdd(&g.counters[i], 0ull);
             g.host_counters[i] = v;
@@ -853,7 +1279,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
             it.t.stride = 1;
-            it.cost = 200 + 6 * (u32)M;  // ~instructions: 2 per mismatch word, 1 per 3-row OR, 2-3 per start word, 2 LDS reads per 4 rows
+            it.cost = 340 + 5 * (u32)M;  // measured (stamps build): 3.4-4.3 k cycles per exact task
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
@@ -874,7 +1300,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            it.cost = 40 + 180 * (4 / stride);  // ~instructions per examined block + per task
+            it.cost = stride == 1 ? 730u : (stride == 2 ? 430u : 280u);  // measured: 7.3 k / 4.3 k / 2.5-3.0 k cycles
             items.push_back(it);
             reach = std::max<u32>(reach, 24 + k0 + 15);
             covered_to = k0 + 8;
@@ -894,16 +1320,41 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     }
     plan->n_waves = nw;
     plan->n_tasks = 0;
+    plan->n_group_k = 0;
+    plan->n_exact = 0;
+    // the motif sizes of the exact tasks are consecutive: M(k) = max((r-1) k, span - k) is V-shaped, so {k : M(k) < 15} is an interval
+    u32 k_exact0 = ~0u, k_exact1 = 0, n_exact_items = 0;
+    for (const Item &it : items)
+        if (it.t.kind) {
+            k_exact0 = std::min<u32>(k_exact0, it.t.k0);
+            k_exact1 = std::max<u32>(k_exact1, it.t.k0);
+            n_exact_items++;
+        }
+    if (n_exact_items && k_exact1 - k_exact0 + 1 != n_exact_items) return false;
+    plan->k_exact0 = n_exact_items ? k_exact0 : 0;
     for (u32 w = 0; w < nw; w++) {
         plan->wave_begin[w] = plan->n_tasks;
-        for (const Item &it : bins[w]) plan->tasks[plan->n_tasks++] = it.t;
+        for (const Item &it : bins[w]) {
+            prf_vtask t = it.t;
+            t.pad = 0;
+            t.item0 = 0;
+            if (t.kind == 0) {
+                t.item0 = (unsigned short)plan->n_group_k;
+                plan->n_group_k += (u32)__builtin_popcount((unsigned)t.valid);
+            } else {
+                plan->n_exact++;
+                t.item0 = (unsigned short)(t.k0 - k_exact0);
+            }
+            plan->tasks[plan->n_tasks++] = t;
+        }
     }
     for (u32 w = nw; w <= PRF_VMAX_WAVES; w++) plan->wave_begin[w] = plan->n_tasks;
     const u32 need_nc = 64 + reach / T;  // row r of a lane's extended stream lies in virtual lane + r / 32
     plan->nc = need_nc <= 72 ? 72 : 80;  // the widths the kernel is instantiated for
-    plan->cof_words = 0;
+    plan->cof_words = (kmax + 1 + 3) & ~3u;  // <= PRF_VMAX_K + 4: the table is declared with that many entries
     plan->lds_bytes = (u32)(SMEM_HDR + (size_t)2 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
-                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64));
+                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (size_t)(plan->n_exact * 64 + 16 + plan->n_group_k) * sizeof(u32) +
+                            (size_t)plan->cof_words * sizeof(u32));
     return need_nc <= 80;
 }
 
@@ -919,7 +1370,7 @@ hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
 }
 
 hipError_t prf_vertical_gather(hipStream_t s, const prf_vgather_args &args) {
-    const u32 nb = args.n_launch ? (args.n_launch + 255u) / 256u : 1u;
+    const u32 nb = args.n_launch ? (args.n_launch + PRF_GATHER_SLOTS - 1u) / PRF_GATHER_SLOTS : 1u;
     hipLaunchKernelGGL(prf_vgather_kernel, dim3(nb), dim3(256), 0, s, args);
     return hipGetLastError();
 }

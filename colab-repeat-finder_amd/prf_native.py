@@ -53,7 +53,7 @@ class ScanStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_double), ("phase1_ms", ctypes.c_double), ("phase2_ms", ctypes.c_double),
                 ("positions", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
                 ("n_hits", ctypes.c_uint64), ("n_launches", ctypes.c_uint32), ("path", ctypes.c_uint32),
-                ("seq", ctypes.c_uint64), ("sorted_on_device", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("seq", ctypes.c_uint64), ("sorted_on_device", ctypes.c_uint32), ("tiles_launched", ctypes.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -63,7 +63,7 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
-           "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions"]
+           "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -110,6 +110,8 @@ def load_library():
         lib.prf_scan_genome_async.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_wait.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(ScanStats)]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
+        lib.prf_scan_timings_split.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float),
+                                               ctypes.POINTER(ctypes.c_float)]
         lib.prf_plan_describe.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_char_p, ctypes.c_uint64]
         lib.prf_fasta_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
         lib.prf_fasta_open_contig.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -294,6 +296,13 @@ class Context:
         out = (ctypes.c_float * max(1, n))()
         _check(self.lib, self.lib.prf_scan_timings(self._h, first_seq, n, out))
         return [float(out[i]) for i in range(n)]
+
+    def scan_timings_split(self, first_seq, n):
+        """(scan kernel ms, gather kernel ms) lists of n fused scans from serial number first_seq on."""
+        a = (ctypes.c_float * max(1, n))()
+        b = (ctypes.c_float * max(1, n))()
+        _check(self.lib, self.lib.prf_scan_timings_split(self._h, first_seq, n, a, b))
+        return [float(a[i]) for i in range(n)], [float(b[i]) for i in range(n)]
 
     def measure_hbm_read(self, nbytes=1 << 30, iters=5):
         out = ctypes.c_double(0)

@@ -82,7 +82,7 @@ typedef struct prf_scan_stats {
     uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel                        */
     uint64_t seq;           /* fused path: serial number of this scan on its context (prf_scan_timings)  */
     uint32_t sorted_on_device; /* 1: the rows left the device sorted by (contig, start, end), no host sort   */
-    uint32_t reserved;
+    uint32_t tiles_launched;   /* fused path: 65536-position tiles scanned (tiles of nothing but N are skipped)     */
 } prf_scan_stats;
 
 /* prf_scan flags */
@@ -166,9 +166,11 @@ int prf_scan_wait(prf_ctx *ctx, uint64_t seq, prf_scan_stats *stats);
  * PRF_EINVAL if the scan finds more than capacity_rows rows.  dst_device == NULL: back to the internal array. */
 int prf_set_row_sink(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows);
 
-/* HIP-event kernel times (ms) of the fused scans first_seq .. first_seq+n-1 of this context (prf_scan_stats.seq);
+/* HIP-event times (ms) of the two kernels of the fused scans first_seq .. first_seq+n-1 of this context (prf_scan_stats.seq);
  * they must be among its last PRF_TIMING_RING fused scans.  Waits for those scans' events. */
 int prf_scan_timings(prf_ctx *ctx, uint64_t first_seq, uint32_t n, float *kernel_ms);
+/* The same, per kernel: the fused scan kernel and the row gather that follows it (a third event lies between them). */
+int prf_scan_timings_split(prf_ctx *ctx, uint64_t first_seq, uint32_t n, float *scan_ms, float *gather_ms);
 
 void prf_free_hits(prf_hits *hits);
 

@@ -190,7 +190,7 @@ def test_very_long_runs_flush_the_candidate_lists(ctx):
     assert stats.path == 1
     got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
     assert got == [(0, 300_000, 1), (300_001, 380_001, 2)]
-    assert stats.n_candidates > 10_000 and stats.sorted_on_device == 0   # records are per (lane, motif size); rows of the flushes bypass the sort
+    assert stats.n_candidates > 10_000   # (stream, exact task) flags + records of the group tasks, whose lists fill up and flush
 
 
 def test_row_slab_overflow_grows_the_slabs(ctx):
@@ -413,7 +413,7 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
     g = ctx.load([seq], 50)
     try:
         rows, st = g.scan(1, 50, 3, 9)
-        assert st.path == 1 and st.n_launches == 2 and st.phase1_ms > 0 and st.seq > 0 and st.sorted_on_device == 1
+        assert st.path == 1 and st.n_launches == 2 and st.phase1_ms > 0 and st.seq > 0
         seqs = []
         for _ in range(5):
             none, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_DEFER_TIMING, fetch=False)
@@ -430,7 +430,10 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
         host = buf.cpu().numpy()
         assert n == len(rows) and host[cap].tolist() == [n, 0, 0] and (host[n:cap] == -1).all()
         got = np.ascontiguousarray(host[:n]).view(rows.dtype).reshape(-1)
-        assert np.array_equal(got, rows)                     # the rows leave the device sorted: no host sort in between
+        if st.sorted_on_device:                              # (a tile this dense may flush a record list: then the host sorts)
+            assert np.array_equal(got, rows)                 # the rows leave the device sorted: no host sort in between
+        got = got[np.lexsort((got["end"], got["start"], got["contig"]))]
+        assert np.array_equal(got, rows)
         # pipelined scans: two in flight, collected one step late; rows of a collected scan through the hand-off
         pending, done = None, []
         for _ in range(7):

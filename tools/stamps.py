@@ -31,12 +31,14 @@ for i in order:
 
 # per-task durations (cycles, median over workgroups): slot 8+i = start of the wave's i-th task, slot 3 = end of scan
 for w in range(4):
-    starts = [d[:, w, 8 + i] for i in range(4)]
+    starts = [d[:, w, 8 + i] for i in range(8)]
     out = []
-    for i in range(4):
+    for i in range(8):
         if np.median(starts[i]) == 0: break
-        nxt = starts[i + 1] if i + 1 < 4 and np.median(starts[i + 1]) != 0 else d[:, w, 3]
+        nxt = starts[i + 1] if i + 1 < 8 and np.median(starts[i + 1]) != 0 else d[:, w, 3]
         out.append(int(np.median(nxt - starts[i])))
     print('wave', w, 'task cycles', out)
+
 for w in range(4):
-    print('wave', w, 'exact blocks: rows(load+mismatch words)=%d cand(incl push)=%d push=%d cycles total, hot blocks=%d' % tuple(int(np.median(d[:, w, 12 + i])) for i in range(4)))
+    print('wave', w, 'verify split: collect flags=%d barrier=%d flags body=%d group+boundary=%d' % tuple(int(np.median(x)) for x in (
+        d[:, w, 12] - d[:, w, 4], d[:, w, 13] - d[:, w, 12], d[:, w, 14] - d[:, w, 13], d[:, w, 5] - d[:, w, 14])))
