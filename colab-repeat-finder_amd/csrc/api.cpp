@@ -370,7 +370,7 @@ static void reset_vcounters(prf_ctx *c) {
     (void)hipMemsetAsync(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64), c->stream);
     if (c->d_block_sum)
         (void)hipMemsetAsync(c->d_block_sum, 0,
-                             ((size_t)(c->slab_slots / PRF_GATHER_SLOTS + 1) + (size_t)(c->slab_slots / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER) + 2)) * sizeof(u32),
+                             ((size_t)(c->slab_slots / 8 + 1) + 2 * (size_t)(c->slab_slots / (8 * PRF_GATHER_SUPER) + 2)) * sizeof(u32),
                              c->stream);
     (void)hipStreamSynchronize(c->stream);
 }
@@ -470,7 +470,7 @@ static int ensure_slabs(prf_ctx *c, u64 nslots, u32 cap) {
         c->d_block_sum = nullptr;
         c->slab_slots = 0;
         c->slab_cap = 0;
-        const size_t n_blocks = (size_t)(nslots / PRF_GATHER_SLOTS + 1) + (size_t)(nslots / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER) + 2);
+        const size_t n_blocks = (size_t)(nslots / 8 + 1) + 2 * (size_t)(nslots / (8 * PRF_GATHER_SUPER) + 2);
         HIPCHK(hipMalloc((void **)&c->d_slabs, nslots * (u64)cap * sizeof(prf_hit_dev)));
         HIPCHK(hipMalloc((void **)&c->d_slab_count, nslots * sizeof(u32)));
         HIPCHK(hipMalloc((void **)&c->d_block_sum, n_blocks * sizeof(u32)));
@@ -491,7 +491,9 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     a.H = g->H; a.L = g->L; a.X = g->X;
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
     a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
-    a.super_off = (lv.n + PRF_GATHER_SLOTS - 1u) / PRF_GATHER_SLOTS;  // the gather's grid
+    // the gather takes 8 launch slots per workgroup on small launches (more workgroups in flight), 64 on large ones
+    a.gather_shift = lv.n <= 8192u ? 3u : 6u;
+    a.super_off = (lv.n + (1u << a.gather_shift) - 1u) >> a.gather_shift;  // the gather's grid
     a.min_repeats = min_repeats; a.min_span = min_span;
     a.tile_info = g->d_tile_info;
     a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
@@ -513,6 +515,7 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     prf_vgather_args ga;
     ga.slabs = c->d_slabs; ga.slab_count = c->d_slab_count; ga.block_sum = c->d_block_sum; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
     ga.super_off = a.super_off;
+    ga.gather_shift = a.gather_shift;
     ga.rows = rows; ga.rows_cap = rows_cap; ga.count_row = count_row;
     ga.counters = a.counters;
     ga.host_counters = host_counters_dev;

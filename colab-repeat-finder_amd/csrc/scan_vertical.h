@@ -9,7 +9,7 @@
 #define PRF_VMAX_K 480       // largest motif size the fused kernel takes (9-bit k field, LDS image width)
 #define PRF_VMAX_TASKS 80
 #define PRF_VMAX_WAVES 4
-#define PRF_GATHER_SLOTS 8u           // launch slots per workgroup of the row gather
+#define PRF_GATHER_SLOTS_MAX 64u      // launch slots per workgroup of the row gather: 8 or 64 (gather_shift 3 / 6)
 #define PRF_GATHER_SUPER 64u          // gather workgroups per second-level sum
 #define PRF_LAUNCH_MIXED 0x80000000u  // launch-list entry: the tile has not-ACGT positions in reach
 
@@ -61,8 +61,9 @@ struct prf_vscan_args {
     u32 flat_base;                 // != ~0u: entry i is the clean tile flat_base + i (no dependent load)
     prf_hit_dev *slabs;            // [launch slot][slab_cap]: the tile's rows, sorted by (start, end)
     u32 *slab_count;               // [launch slot]: rows the tile produced (> slab_cap: the slab overflowed)
-    u32 *block_sum;                // [launch slot / PRF_GATHER_SLOTS]: rows stored by those slots (zero when the kernel starts);
-    u32 super_off;                 // from block_sum[super_off] on: the same per PRF_GATHER_SLOTS * PRF_GATHER_SUPER slots
+    u32 *block_sum;                // [launch slot >> gather_shift]: rows stored by those slots (zero when the kernel starts);
+    u32 super_off;                 // from block_sum[super_off] on: the same per PRF_GATHER_SUPER gather workgroups, then their tickets
+    u32 gather_shift;              // log2 of the launch slots per gather workgroup
     u32 slab_cap;
     u32 min_repeats, min_span;
     const uint4 *tile_info;        // [tile]: {contig, 0, contig base lo, hi}
@@ -77,6 +78,7 @@ struct prf_vgather_args {
     const u32 *slab_count;
     u32 *block_sum;                // read, then cleared by the last workgroup
     u32 super_off;
+    u32 gather_shift;
     u32 slab_cap;
     u32 n_launch;
     prf_hit_dev *rows;             // the compact row array, sorted by (contig, start, end) because the slabs are

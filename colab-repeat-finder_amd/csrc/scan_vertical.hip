@@ -113,7 +113,8 @@ struct TileCtx {
     u32 slab_cap;
     u32 min_repeats, min_span;
     u32 lin_off;              // byte offset of the linear window in LDS
-    u32 has_lin;              // the linear window is staged (clean tiles)
+    u32 has_lin;              // the linear window is staged (clean tiles: from the start; tiles with N in reach: after the scan)
+    u32 xwin_off;             // byte offset of the not-ACGT plane's window (tiles with N in reach, after the scan), else 0
     u32 cof_off;              // byte offset of the cofactor table in LDS
     u32 hotw_off;             // byte offset of the exact tasks' stream words in LDS: [exact task][lane], then (k | M << 16) per task
     u32 n_exact;              // exact tasks of the plan: motif sizes k_exact0 .. k_exact0 + n_exact - 1, task index = k - k_exact0
@@ -291,19 +292,23 @@ __device__ __forceinline__ u64 look64(prf_lds_cu32 *plane, u32 q) {
     const u32 w0 = plane[w], w1 = plane[w + 1], w2 = plane[w + 2];
     return (u64)__builtin_amdgcn_alignbit(w1, w0, sft) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sft) << 32);
 }
-// mismatch bits of window positions q .. q+31 / q+63 against q+k ..; the caller guarantees q + k + 96 <= WIN_POS
-__device__ __forceinline__ u32 win_mismatch32(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 q, u32 k) {
-    return (look32(h, q) ^ look32(h, q + k)) | (look32(l, q) ^ look32(l, q + k));
-}
-__device__ __forceinline__ u64 win_mismatch64(prf_lds_cu32 *h, prf_lds_cu32 *l, u32 q, u32 k) {
-    return (look64(h, q) ^ look64(h, q + k)) | (look64(l, q) ^ look64(l, q + k));
-}
-
 struct WinCtx {
-    prf_lds_cu32 *h, *l, *cof;
+    prf_lds_cu32 *h, *l, *x, *cof;  // x: the not-ACGT plane's window (tiles with N in reach), nullptr for clean tiles
     u64 win0;  // global position of window bit 0
     u32 min_repeats, min_span;
 };
+
+// mismatch bits of window positions q .. q+31 / q+63 against q+k ..; the caller guarantees q + k + 96 <= WIN_POS
+__device__ __forceinline__ u32 win_mismatch32(const WinCtx &wc, u32 q, u32 k) {
+    u32 r = (look32(wc.h, q) ^ look32(wc.h, q + k)) | (look32(wc.l, q) ^ look32(wc.l, q + k));
+    if (wc.x) r |= look32(wc.x, q) | look32(wc.x, q + k);
+    return r;
+}
+__device__ __forceinline__ u64 win_mismatch64(const WinCtx &wc, u32 q, u32 k) {
+    u64 r = (look64(wc.h, q) ^ look64(wc.h, q + k)) | (look64(wc.l, q) ^ look64(wc.l, q + k));
+    if (wc.x) r |= look64(wc.x, q) | look64(wc.x, q + k);
+    return r;
+}
 
 __device__ __forceinline__ u32 min_matches32(u32 k, u32 min_repeats, u32 min_span) {
     const u32 a = (min_repeats - 1u) * k, b = min_span > k ? min_span - k : 0u;
@@ -315,7 +320,7 @@ __device__ __forceinline__ u32 min_matches32(u32 k, u32 min_repeats, u32 min_spa
 __device__ __forceinline__ u64 win_run_end(const WinCtx &wc, u32 from, u32 k) {
     for (;;) {
         if (from + k + 96u > WIN_POS) return run_end(wc.win0 + from, k);
-        const u64 m2 = win_mismatch64(wc.h, wc.l, from, k);
+        const u64 m2 = win_mismatch64(wc, from, k);
         if (m2) return wc.win0 + from + (u64)__builtin_ctzll(m2);
         from += 64u;
     }
@@ -328,7 +333,7 @@ __device__ __forceinline__ bool win_motif_is_repeat(const WinCtx &wc, u32 a, u32
         const u32 d = cf & 255u, need = k - d;
         bool has = true;
         for (u32 off = 0; off < need; off += 32) {
-            u32 mm = win_mismatch32(wc.h, wc.l, a + off, d);
+            u32 mm = win_mismatch32(wc, a + off, d);
             const u32 left = need - off;
             if (left < 32) mm &= (1u << left) - 1u;
             if (mm) {
@@ -363,8 +368,15 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
     const u64 hhi = (u64)__builtin_amdgcn_alignbit(a3, a2, sft) | ((u64)__builtin_amdgcn_alignbit(a4, a3, sft) << 32);
     const u64 llo = (u64)__builtin_amdgcn_alignbit(b1, b0, sft) | ((u64)__builtin_amdgcn_alignbit(b2, b1, sft) << 32);
     const u64 lhi = (u64)__builtin_amdgcn_alignbit(b3, b2, sft) | ((u64)__builtin_amdgcn_alignbit(b4, b3, sft) << 32);
+    u64 xlo = 0, xhi = 0;
+    if (wc.x) {
+        const u32 c0 = wc.x[w], c1 = wc.x[w + 1], c2 = wc.x[w + 2], c3 = wc.x[w + 3], c4 = wc.x[w + 4];
+        xlo = (u64)__builtin_amdgcn_alignbit(c1, c0, sft) | ((u64)__builtin_amdgcn_alignbit(c2, c1, sft) << 32);
+        xhi = (u64)__builtin_amdgcn_alignbit(c3, c2, sft) | ((u64)__builtin_amdgcn_alignbit(c4, c3, sft) << 32);
+    }
     const u32 M = min_matches32(k, wc.min_repeats, wc.min_span);
-    const u64 m = (hlo ^ shr128(hlo, hhi, k)) | (llo ^ shr128(llo, lhi, k));  // bit i = mismatch at window position q - 1 + i
+    // bit i = mismatch at window position q - 1 + i
+    const u64 m = (hlo ^ shr128(hlo, hhi, k)) | (llo ^ shr128(llo, lhi, k)) | xlo | shr128(xlo, xhi, k);
     u64 r = ~m;  // -> bit i: positions i .. i+M-1 all match (M <= 14: three doublings and a rest)
     if (M >= 2) r &= r >> 1;
     if (M >= 4) r &= r >> 2;
@@ -382,7 +394,7 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
         bool rep = false;
         for (u32 cf = cof_k; cf && !rep; cf >>= 4) {
             const u32 d = cf & 15u;
-            const u64 md = (hlo ^ shr128(hlo, hhi, d)) | (llo ^ shr128(llo, lhi, d));
+            const u64 md = (hlo ^ shr128(hlo, hhi, d)) | (llo ^ shr128(llo, lhi, d));  // (no N inside a run of >= M >= k matches)
             rep = ((md >> i) & ((1ull << (k - d)) - 1ull)) == 0;
         }
         if (rep) continue;
@@ -401,7 +413,7 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
 __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx &wc, u32 q, u32 k, u32 S) {
     const u32 M = min_matches32(k, wc.min_repeats, wc.min_span);
     const u32 back = 8u * S;
-    const u64 m = win_mismatch64(wc.h, wc.l, q - 32u, k);  // bit i = mismatch at window position q - 32 + i
+    const u64 m = win_mismatch64(wc, q - 32u, k);  // bit i = mismatch at window position q - 32 + i
     const u32 cof_k = wc.cof[k];
     u32 leaders = 0;  // bit j: group j of the stream is all-match, the first examined one of its run, and the run starts in the tile
     u32 nbs = 0;      // 5 bits per group: matches directly before it
@@ -425,19 +437,19 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
             if (motif_is_repeat(wc.win0 + a, k)) continue;
         } else {
             const u32 d1 = cof_k & 255u, d2 = (cof_k >> 8) & 255u, d3 = (cof_k >> 16) & 255u;
-            const u32 mm1 = win_mismatch32(wc.h, wc.l, a, d1 ? d1 : 1u);
-            const u32 mm2 = win_mismatch32(wc.h, wc.l, a, d2 ? d2 : 1u);
-            const u32 mm3 = win_mismatch32(wc.h, wc.l, a, d3 ? d3 : 1u);
+            const u32 mm1 = win_mismatch32(wc, a, d1 ? d1 : 1u);
+            const u32 mm2 = win_mismatch32(wc, a, d2 ? d2 : 1u);
+            const u32 mm3 = win_mismatch32(wc, a, d3 ? d3 : 1u);
             bool rep = false;
             for (u32 ci = 0; ci < 4u && !rep; ci++) {
                 const u32 d = (cof_k >> (8u * ci)) & 255u;
                 if (d == 0) break;
                 const u32 need = k - d;
-                u32 mm = ci == 0 ? mm1 : (ci == 1 ? mm2 : (ci == 2 ? mm3 : win_mismatch32(wc.h, wc.l, a, d)));
+                u32 mm = ci == 0 ? mm1 : (ci == 1 ? mm2 : (ci == 2 ? mm3 : win_mismatch32(wc, a, d)));
                 if (need < 32) mm &= (1u << need) - 1u;
                 rep = mm == 0;
                 for (u32 off = 32; off < need && rep; off += 32) {
-                    u32 m2 = win_mismatch32(wc.h, wc.l, a + off, d);
+                    u32 m2 = win_mismatch32(wc, a + off, d);
                     const u32 left = need - off;
                     if (left < 32) m2 &= (1u << left) - 1u;
                     rep = m2 == 0;
@@ -450,7 +462,7 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
         if (seen) {
             b = wc.win0 + (q - 32u + gb + 8u) + (u64)__builtin_ctzll(seen);
         } else {
-            const u64 m2 = win_mismatch64(wc.h, wc.l, q + 32u, k);  // (q + 32 + k + 96 <= WIN_POS for every stream of the tile)
+            const u64 m2 = win_mismatch64(wc, q + 32u, k);  // (q + 32 + k + 96 <= WIN_POS for every stream of the tile)
             b = m2 ? wc.win0 + (q + 32u) + (u64)__builtin_ctzll(m2) : win_run_end(wc, q + 96u, k);
         }
         if (b - (wc.win0 + a) < (u64)M) continue;
@@ -465,7 +477,7 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
 __device__ __forceinline__ void boundary_item(const TileCtx &tc, const WinCtx &wc, bool fast, u32 k, u32 S) {
     const u64 tile_end = tc.tile_base + PRF_TILE;
     const u32 back = 8u * S;
-    const u64 mm = fast ? win_mismatch64(wc.h, wc.l, 64u + PRF_TILE - 32u, k) : tile_mismatch64(tile_end - 32, k);
+    const u64 mm = fast ? win_mismatch64(wc, 64u + PRF_TILE - 32u, k) : tile_mismatch64(tile_end - 32, k);
     const u32 lo = (u32)mm;  // bit i = mismatch at tile_end - 32 + i
     const u32 c = lo ? (u32)__builtin_clz(lo) : 32u;
     if (c == 0 || c >= back) return;
@@ -510,6 +522,7 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
     WinCtx wc;
     wc.h = (prf_lds_cu32 *)(prf_smem + tc.lin_off);
     wc.l = wc.h + 2 * LW;
+    wc.x = tc.xwin_off ? (prf_lds_cu32 *)(prf_smem + tc.xwin_off) : nullptr;
     wc.cof = (prf_lds_cu32 *)(prf_smem + tc.cof_off);
     wc.win0 = tc.tile_base - 64;
     wc.min_repeats = tc.min_repeats;
@@ -520,7 +533,7 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
     u32 n_flags = 0;
     if (tc.n_exact) {
         constexpr u32 MAX_EXACT = SMALL_M - 1;  // motif sizes 1 .. 14 at most
-        constexpr u32 FLAG_CAP_WAVE = 1024;
+        constexpr u32 FLAG_CAP_WAVE = 512;
         typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
         prf_lds_u16 *flags = (prf_lds_u16 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 16);  // 4 lists of FLAG_CAP_WAVE
         prf_lds_u32 *flag_cnt = (prf_lds_u32 *)(prf_smem + 172);                         // [MAX_WAVES]
@@ -569,8 +582,9 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
             for (u32 idx = tid; idx < total; idx += (u32)NTH) {
                 const u32 slot_idx = idx < e0 ? idx : (idx < e1 ? FLAG_CAP_WAVE + (idx - e0) : (idx < e2 ? 2 * FLAG_CAP_WAVE + (idx - e1) : 3 * FLAG_CAP_WAVE + (idx - e2)));
                 const u32 f = flags[slot_idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
-                // (the tile's first stream looks at positions in front of the tile, where N is possible: general routine)
-                if (fast && (frl | fbit)) win_verify_flag(tc, wc, frl, fbit, k);
+                // (a clean tile's first stream looks at positions in front of the tile, where N is possible and the window
+                // has no not-ACGT plane: general routine)
+                if (fast && ((frl | fbit) || wc.x)) win_verify_flag(tc, wc, frl, fbit, k);
                 else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u, true);
             }
         } else {  // a tile of long runs: every thread takes its own flags
@@ -598,7 +612,7 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
                     const u32 bit = (u32)__builtin_ctz(word);
                     word &= word - 1;
                     const u32 sq = (bit * 64u + rl) * T;
-                    if (fast && sq >= 32u) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
+                    if (fast && (sq >= 32u || wc.x)) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
                     else verify_stream(tc.tile_base + sq, k, sc, true);
                 }
             } else {  // boundary item
@@ -1009,6 +1023,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             tc.min_span = g.min_span;
             tc.lin_off = lin_off;
             tc.has_lin = hasx ? 0u : 1u;
+            tc.xwin_off = 0u;
             tc.hotw_off = lin_off + (u32)(2 * LW * sizeof(u64) + MAX_WAVES * REC_PER_WAVE * sizeof(u64));
             tc.n_exact = g.plan.n_exact;
             tc.k_exact0 = g.plan.k_exact0;
@@ -1041,6 +1056,34 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     }
     PRF_STAMP(3);
     __syncthreads();  // the image is dead from here on: the row list may lie there
+    if (hasx) {
+        // A tile with N in reach kept its not-ACGT plane where the linear window belongs.  Now that the scan is over the
+        // windows of all three linear planes are staged -- H and L in the window's place, X in the dead image behind the row
+        // and flag lists -- so that this tile, too, verifies from LDS (a look at the global planes is a memory round trip).
+        constexpr u32 xwin_off = (u32)SMEM_HDR + (u32)ROW_CAP_LDS * 16u + 4u * 512u * 2u;
+        static_assert(xwin_off + LW * 8 <= SMEM_HDR + 2 * RG * NC * 16, "the X window must fit the dead image");
+        prf_lds_u64 *xwin = (prf_lds_u64 *)(prf_smem + xwin_off);
+        const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;
+        constexpr int NR = (3 * LW + NTH - 1) / NTH;
+        u64 v[NR];
+        static_for<0, NR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * NTH;
+            v[i] = idx < LW ? g.H[w0 + idx] : (idx < 2 * LW ? g.L[w0 + idx - LW] : (idx < 3 * LW ? g.X[w0 + idx - 2 * LW] : 0ull));
+        });
+        static_for<0, NR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * NTH;
+            if (idx < 2 * LW) lin[idx] = v[i];
+            else if (idx < 3 * LW) xwin[idx - 2 * LW] = v[i];
+        });
+        if (tid == 0) {
+            TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
+            tcw->has_lin = 1u;
+            tcw->xwin_off = xwin_off;
+        }
+        __syncthreads();
+    }
     PRF_STAMP(4);
 
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's LDS list, or nothing ----
@@ -1060,8 +1103,22 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     // Rank of a row = number of rows of the list with a smaller key; keys are distinct ((start, end) pairs never collide
     // between motif sizes).
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
-    const u32 n_listed = *smem_row_cnt();
-    const u32 n_direct = *smem_direct_cnt();
+    u32 n_listed = *smem_row_cnt();
+    u32 n_direct = *smem_direct_cnt();
+    if (n_direct && n_listed + n_direct <= (u32)ROW_CAP_LDS && n_direct <= tc.slab_cap) {
+        // Rows that went straight to the slab (a wave emptied its record list in the middle of the scan) and still fit the
+        // list: read them back and sort them with the others -- the tile stays sorted.
+        if ((u32)tid < n_direct) {
+            const prf_hit_dev h = tc.slab[tid];
+            const u64 a = h.start + tc.contig_base, end = h.end + tc.contig_base, span = end - a;
+            smem_row_keys()[n_listed + tid] = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
+            smem_row_ks()[n_listed + tid] = h.k;
+            smem_row_ends()[n_listed + tid] = end;
+        }
+        __syncthreads();  // wave-uniform condition: every thread gets here
+        n_listed += n_direct;
+        n_direct = 0;
+    }
     const u32 n_sorted = n_listed < (u32)ROW_CAP_LDS ? n_listed : (u32)ROW_CAP_LDS;
     const u32 n_rows = n_sorted + n_direct;  // rows beyond the list's capacity were counted in n_direct
     if (n_sorted) {
@@ -1107,8 +1164,8 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         g.slab_count[slot] = n_rows;
         const u32 stored = n_rows < tc.slab_cap ? n_rows : tc.slab_cap;
         if (stored) {  // rows in front of a gather workgroup's slots: two levels of sums
-            atomicAdd(&g.block_sum[slot / PRF_GATHER_SLOTS], stored);
-            atomicAdd(&g.block_sum[g.super_off + slot / (PRF_GATHER_SLOTS * PRF_GATHER_SUPER)], stored);
+            atomicAdd(&g.block_sum[slot >> g.gather_shift], stored);
+            atomicAdd(&g.block_sum[g.super_off + ((slot >> g.gather_shift) / PRF_GATHER_SUPER)], stored);
         }
         if (n_rows > tc.slab_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
         if (n_direct) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
@@ -1124,30 +1181,31 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
 // counter block of the next scan (no memset call).
 __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     __shared__ u64 part[4];
-    __shared__ u32 offs[PRF_GATHER_SLOTS + 1];  // in words (3 per row)
+    __shared__ u32 offs[PRF_GATHER_SLOTS_MAX + 1];  // in words (3 per row)
     __shared__ u64 ticket_lds;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 first = blockIdx.x * PRF_GATHER_SLOTS;
+    const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) or 64
+    const u32 first = blockIdx.x << g.gather_shift;
     const u32 my_super = blockIdx.x / PRF_GATHER_SUPER;
     u64 before = 0;
     for (u32 i = tid; i < my_super; i += 256u) before += g.block_sum[g.super_off + i];
     if (tid < blockIdx.x - my_super * PRF_GATHER_SUPER) before += g.block_sum[my_super * PRF_GATHER_SUPER + tid];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
-    if (tid < 64u) {  // exclusive scan of the 8 counts (loaded in parallel)
-        u32 c = (tid < PRF_GATHER_SLOTS && first + tid < g.n_launch) ? g.slab_count[first + tid] : 0u;
+    if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel)
+        u32 c = (tid < n_slots && first + tid < g.n_launch) ? g.slab_count[first + tid] : 0u;
         c = 3u * (c < g.slab_cap ? c : g.slab_cap);
         u32 incl = c;
-        for (int o = 1; o < (int)PRF_GATHER_SLOTS; o <<= 1) {
+        for (int o = 1; o < 64; o <<= 1) {
             const u32 up = __shfl_up(incl, o, 64);
             if ((int)tid >= o) incl += up;
         }
-        if (tid < PRF_GATHER_SLOTS) offs[tid + 1] = incl;
+        offs[tid + 1] = incl;
         if (tid == 0) offs[0] = 0;
     }
     __syncthreads();
     const u64 base0 = part[0] + part[1] + part[2] + part[3];  // rows in front of this workgroup's slots
-    const u32 n_words = offs[PRF_GATHER_SLOTS];
+    const u32 n_words = offs[n_slots];
     // rows beyond the capacity stay behind: the host sees the total beyond the capacity, grows the array, rescans
     const u64 room_rows = base0 < g.rows_cap ? g.rows_cap - base0 : 0;
     const u64 room_words = 3ull * room_rows;
@@ -1160,9 +1218,11 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
             const u32 w = w0 + 256u * (u32)j;
             v[j] = 0;
             if (w < n_copy) {
-                u32 lo = 0;  // the slot whose words hold w: offs[lo] <= w < offs[lo + 1]
-#pragma unroll
-                for (u32 i = 1; i < PRF_GATHER_SLOTS; i++) lo += offs[i] <= w ? 1u : 0u;
+                u32 lo = 0, hi = n_slots;  // the slot whose words hold w: offs[lo] <= w < offs[lo + 1]
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (offs[mid] <= w) lo = mid; else hi = mid;
+                }
                 v[j] = reinterpret_cast<const u64 *>(g.slabs + (u64)(first + lo) * g.slab_cap)[w - offs[lo]];
             }
         }
@@ -1175,15 +1235,24 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     // the workgroup of the last slots knows the total
     if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_words / 3u);
     __syncthreads();  // every wave's stores and atomics are issued; the barrier waits for outstanding memory operations
-    if (tid == 0) ticket_lds = atomicAdd(&g.counters[PRF_CNT_TICKET], 1ull);
+    // Finishing tickets in two levels (one word takes ~90 atomics per microsecond: thousands of workgroups on ONE ticket word
+    // would cost more than the copy): a ticket per 64 workgroups, and the last of each 64 draws a global one.
+    const u32 n_supers = (gridDim.x - 1u) / PRF_GATHER_SUPER + 1u;
+    if (tid == 0) {
+        const u32 in_super = my_super + 1u < n_supers ? PRF_GATHER_SUPER : gridDim.x - my_super * PRF_GATHER_SUPER;
+        u64 t = 0;
+        if (atomicAdd(&g.block_sum[g.super_off + n_supers + my_super], 1u) == in_super - 1u)
+            t = atomicAdd(&g.counters[PRF_CNT_TICKET], 1ull) + 1ull;
+        ticket_lds = t;  // n_supers: this workgroup is the last one of the whole grid
+    }
     __syncthreads();
-    // ---- the last workgroup to draw a ticket hands the counter block to the host.  The counters are only ever touched
+    // ---- the last workgroup hands the counter block to the host.  The counters are only ever touched
     // by device-scope atomics, performed at the coherence point, and every workgroup's were issued in front of the
     // barrier that precedes its ticket (s_waitcnt vmcnt(0) before s_barrier), so they precede the last ticket.  Every
-    // other workgroup has read its block sums by then: they are cleared for the next scan.
-    if (ticket_lds == (u64)gridDim.x - 1ull) {
+    // other workgroup has read its sums by then: they are cleared for the next scan.
+    if (ticket_lds == (u64)n_supers) {
+        for (u32 i = tid; i < 2u * n_supers; i += 256u) g.block_sum[g.super_off + i] = 0;
         for (u32 i = tid; i < gridDim.x; i += 256u) g.block_sum[i] = 0;
-        for (u32 i = tid; i <= (gridDim.x - 1u) / PRF_GATHER_SUPER; i += 256u) g.block_sum[g.super_off + i] = 0;
         for (u32 i = tid; i < (u32)PRF_CNT_N; i += 256u) {
             const u64 v = atomicAdd(&g.counters[i], 0ull);
             g.host_counters[i] = v;
@@ -1279,7 +1348,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
             it.t.stride = 1;
-            it.cost = 340 + 5 * (u32)M;  // measured (stamps build): 3.4-4.3 k cycles per exact task
+            it.cost = 240 + 15 * (u32)M;  // measured (stamps build): 3.3 k (M = 6) ... 4.5 k (M = 14) cycles per exact task
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
@@ -1300,7 +1369,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            it.cost = stride == 1 ? 730u : (stride == 2 ? 430u : 280u);  // measured: 7.3 k / 4.3 k / 2.5-3.0 k cycles
+            it.cost = stride == 1 ? 740u : (stride == 2 ? 480u : 300u);  // measured: 7.4 k / 4.8 k / 3.0 k cycles
             items.push_back(it);
             reach = std::max<u32>(reach, 24 + k0 + 15);
             covered_to = k0 + 8;
@@ -1370,7 +1439,8 @@ hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
 }
 
 hipError_t prf_vertical_gather(hipStream_t s, const prf_vgather_args &args) {
-    const u32 nb = args.n_launch ? (args.n_launch + PRF_GATHER_SLOTS - 1u) / PRF_GATHER_SLOTS : 1u;
+    const u32 n_slots = 1u << args.gather_shift;
+    const u32 nb = args.n_launch ? (args.n_launch + n_slots - 1u) / n_slots : 1u;
     hipLaunchKernelGGL(prf_vgather_kernel, dim3(nb), dim3(256), 0, s, args);
     return hipGetLastError();
 }
