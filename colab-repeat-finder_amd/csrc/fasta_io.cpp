@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -238,24 +239,48 @@ int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out) {
                 fclose(fi);
                 if (found && lb > 0 && lw >= lb) {
                     if (FILE *f = fopen(path, "rb")) {
-                        const unsigned long long raw = len + (len / lb + 1) * (lw - lb);
-                        std::string buf(raw, '\0');
-                        bool ok = fseeko(f, (off_t)off, SEEK_SET) == 0;
-                        const size_t got = ok ? fread(&buf[0], 1, raw, f) : 0;
+                        // the index is untrusted input: the span it names must lie inside the file, and the line in front of
+                        // it must be the header of the record asked for (a stale index may point into another record of the
+                        // same length); anything else -> the full parse below
+                        struct stat sb;
+                        bool ok = fstat(fileno(f), &sb) == 0 && off <= (unsigned long long)sb.st_size;
+                        const unsigned long long room = ok ? (unsigned long long)sb.st_size - off : 0;
+                        unsigned long long raw = len + (len / lb + 1) * (lw - lb);
+                        if (lw - lb > 8 || len > room) ok = false;
+                        if (raw > room) raw = room;
+                        if (ok) {  // header check: bytes in front of `off` are ">name" + optional description + newline
+                            const unsigned long long back = std::min<unsigned long long>(off, 4096);
+                            std::string head((size_t)back, '\0');
+                            ok = back > 0 && fseeko(f, (off_t)(off - back), SEEK_SET) == 0 && fread(&head[0], 1, (size_t)back, f) == back &&
+                                 head.back() == '\n';
+                            if (ok) {
+                                size_t ls = head.rfind('\n', head.size() - 2);
+                                ls = ls == std::string::npos ? (back == off ? 0 : std::string::npos) : ls + 1;
+                                ok = ls != std::string::npos && head[ls] == '>' && head.compare(ls + 1, want.size(), want) == 0 &&
+                                     (ls + 1 + want.size() >= head.size() || isspace((unsigned char)head[ls + 1 + want.size()]));
+                            }
+                        }
+                        std::unique_ptr<prf_fasta> fa;
+                        if (ok) {
+                            std::string buf((size_t)raw, '\0');
+                            ok = fseeko(f, (off_t)off, SEEK_SET) == 0;
+                            const size_t got = ok ? fread(&buf[0], 1, (size_t)raw, f) : 0;
+                            fa.reset(new prf_fasta());
+                            fa->names.emplace_back(want);
+                            fa->seqs.emplace_back();
+                            prf_seq &seq = fa->seqs.back();
+                            size_t stop = 0;  // a '>' inside the span: the index does not match the file
+                            while (stop < got && buf[stop] != '>') stop++;
+                            append_clean(seq, buf.data(), buf.data() + stop);
+                            if (seq.n > len) seq.n = len;
+                            ok = seq.size() == len;
+                        }
                         fclose(f);
-                        prf_fasta *fa = new prf_fasta();
-                        fa->names.emplace_back(want);
-                        fa->seqs.emplace_back();
-                        prf_seq &seq = fa->seqs.back();
-                        size_t stop = 0;  // a '>' inside the span: the index does not match the file
-                        while (stop < got && buf[stop] != '>') stop++;
-                        append_clean(seq, buf.data(), buf.data() + stop);
-                        if (seq.n > len) seq.n = len;
-                        if (seq.size() == len) {
-                            *out = fa;
+                        if (ok) {
+                            *out = fa.release();
                             return PRF_OK;
                         }
-                        delete fa;  // stale index: fall through to the full parse
+                        // stale or damaged index: fall through to the full parse
                     }
                 }
             }
@@ -275,6 +300,8 @@ int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out) {
         return PRF_OK;
     } catch (const std::bad_alloc &) {
         return prf_set_error(PRF_ENOMEM, "prf_fasta_open_contig: out of memory reading %s", path);
+    } catch (...) {  // nothing may cross the C boundary
+        return prf_set_error(PRF_EINVAL, "prf_fasta_open_contig: unexpected failure reading %s", path);
     }
 }
 

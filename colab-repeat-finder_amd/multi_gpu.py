@@ -106,9 +106,9 @@ def gather_rows(local_rows, dist, torch, device):
 class ShardError(RuntimeError):
     """A rank's scan failed; raised on EVERY rank with the failing rank's message, before any row collective."""
 
-    def __init__(self, rank, kind, message):
+    def __init__(self, rank, kind, message, code=None):
         super().__init__(f"rank {rank}: {kind}: {message}")
-        self.rank, self.kind, self.message = rank, kind, message
+        self.rank, self.kind, self.message, self.code = rank, kind, message, code
 
 
 def agree_or_raise(error, dist, torch, device):
@@ -120,9 +120,10 @@ def agree_or_raise(error, dist, torch, device):
     if int(flag.item()) == 0:
         return
     msgs = [None] * world
-    dist.all_gather_object(msgs, None if error is None else (type(error).__name__, str(getattr(error, "message", error))))
+    dist.all_gather_object(msgs, None if error is None else (type(error).__name__, str(getattr(error, "message", error)),
+                                                             getattr(error, "code", None)))
     bad = next(i for i, m in enumerate(msgs) if m is not None)
-    raise ShardError(bad, msgs[bad][0], msgs[bad][1])
+    raise ShardError(bad, *msgs[bad])
 
 
 def scan_contigs_sharded(contigs, settings, scan_fn, dist, torch, device):

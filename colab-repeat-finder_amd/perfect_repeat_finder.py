@@ -162,19 +162,30 @@ def _scan_whole_fasta(fasta, bed_path, fs, report):
         raise
 
 
-def _gpu_scan_contigs(entries, settings):
-    """scan_fn of multi_gpu.scan_contigs_sharded: this rank's contigs as one resident genome, one scan."""
+def _gpu_scan_parts(entries, settings, parts):
+    """This rank's share: its contigs as one resident genome, the parts it owns selected, one scan.  entries: FASTA entries
+    (native memory); parts: (index into entries, begin, end).  Returns the numpy row array (contig = index into entries)."""
     ctx = prf_native.default_context()
-    rows, _stats = ctx.scan([(e.addr, e.length) for e in entries], *settings)
-    return rows if len(rows) else []
+    genome = ctx.load([(e.addr, e.length) for e in entries], settings[1])
+    try:
+        genome.select(parts)
+        rows, _stats = genome.scan(*settings)
+    finally:
+        genome.free()
+    return rows
 
 
-def _scan_whole_fasta_sharded(fasta, bed_path, fs, report, scan_fn=None):
+def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     """The same under `python -m torch.distributed.run --nproc-per-node N perfect_repeat_finder.py genome.fa`: one
-    process per GPU, contigs dealt to the ranks longest first, every rank scans its share, ONE gather of the rows
-    (RCCL; PRF_DIST_BACKEND=gloo for CPU tensors), rank 0 writes the BED in FASTA order.  Replaces the reference's
-    interval fan-out over Hail Batch jobs and its `cat | sort | uniq` merge
-    (hail_batch_pipeline/run_hail_batch_pipeline.py:76-77,115-123,151-153) on one node, with exact whole-contig rows."""
+    process per GPU.  The genome is cut into N shares of equal size at tile multiples (multi_gpu.plan_parts: a contig longer
+    than a share is split; a row belongs to the share that holds its first position, so nothing is repaired afterwards);
+    every rank reads ONLY the contigs its share touches (by seeking, if a .fai index lies next to the file), scans its share
+    and writes its rows -- a contiguous piece of the final BED, because the shares are in genome order -- to a part file;
+    rank 0 concatenates the parts.  Replaces the reference's interval fan-out over Hail Batch jobs and its
+    `cat | sort | uniq` merge (hail_batch_pipeline/run_hail_batch_pipeline.py:76-77,115-123,151-153) on one node, with exact
+    whole-contig rows.  Collectives: one all_reduce of the per-contig row counts (RCCL; PRF_DIST_BACKEND=gloo for CPU
+    tensors) and an error flag; the rows themselves travel through the part files."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     import multi_gpu
@@ -186,23 +197,64 @@ def _scan_whole_fasta_sharded(fasta, bed_path, fs, report, scan_fn=None):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if started_here:
         dist.init_process_group(backend)
+    device = "cuda" if backend == "nccl" else "cpu"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    part_path = f"{bed_path}.part{rank}"
     try:
-        entries = list(fasta)
-        settings = (fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
+        index, whole = prf_native.fasta_index(path)          # [(name, length)]; whole: the parsed file if there was no index
+        lens = [n for _name, n in index]
+        shares = multi_gpu.plan_parts(lens, world, prf_native.tile_positions())
+        mine = shares[rank]
+        needed = sorted({c for c, _b, _e in mine})
+        counts = np.zeros(len(index), dtype=np.int64)
+        error = None
         try:
-            rows = multi_gpu.scan_contigs_sharded(entries, settings, scan_fn or _gpu_scan_contigs, dist, torch,
-                                                  "cuda" if backend == "nccl" else "cpu")
-        except prf_native.PrfError as exc:
-            if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
-                raise ValueError(exc.message) from None
+            if whole is not None:
+                entries = [whole[c] for c in needed]
+            else:
+                readers = [prf_native.Fasta(path, only=index[c][0]) for c in needed]    # one record each, by seeking
+                entries = [r[0] for r in readers]
+            local = {c: i for i, c in enumerate(needed)}
+            settings = (fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
+            rows = (scan_fn or _gpu_scan_parts)(entries, settings, [(local[c], b, e) for c, b, e in mine]) if mine else []
+            rows = np.asarray(rows, dtype=multi_gpu.ROW_DTYPE)
+            per_local = prf_native.write_bed(part_path, entries, rows)                  # motif text from this rank's own contigs
+            for c, n_rows in zip(needed, per_local):
+                counts[c] = n_rows
+        except Exception as exc:      # noqa: BLE001 -- whatever it is, the peers must hear about it
+            error = exc
+        try:
+            multi_gpu.agree_or_raise(error, dist, torch, device)
+        except multi_gpu.ShardError as exc:
+            if exc.kind == "PrfError" and exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
+                raise ValueError(exc.message) from None     # what the single-process path raises
             raise
-        if dist.get_rank() == 0:
-            counts = prf_native.write_bed(bed_path, entries, rows)
-            for e, c in zip(entries, counts):
-                report(e, c)
+        total = torch.from_numpy(counts).to(device)
+        dist.all_reduce(total)
+        dist.barrier()                                        # every part file is complete
+        if rank == 0:
+            with open(bed_path, "wb") as out:
+                for r in range(world):
+                    with open(f"{bed_path}.part{r}", "rb") as f:
+                        while True:
+                            chunk = f.read(1 << 24)
+                            if not chunk:
+                                break
+                            out.write(chunk)
+            class _E:                                         # what report() reads: name and length
+                def __init__(self, name, n):
+                    self.name, self._n = name, n
+                def __len__(self):
+                    return self._n
+            for (name, n), c in zip(index, total.cpu().tolist()):
+                report(_E(name, n), int(c))
         dist.barrier()
-        return dist.get_rank() == 0
+        return rank == 0
     finally:
+        try:
+            os.remove(part_path)
+        except OSError:
+            pass
         if started_here:
             dist.destroy_process_group()
 
@@ -214,16 +266,17 @@ def _scan_fasta(args, parser):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch  # noqa: F401  before libprf.so is loaded: PyTorch brings its own HIP runtime (load order)
     if not args.interval:
-        entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
         # the reference crashes here without --interval (:139); scan every contig whole instead
         def report(entry, n_rows):
             print(f"Processing {entry.name} ({len(entry):,d} bp)")
             print(f"Found {n_rows:,d} repeats")
-        _check_settings(args)
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:                # one process per GPU: contigs sharded over the ranks
-            if _scan_whole_fasta_sharded(entries, bed_path, args, report):
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:                # one process per GPU: the genome sharded over the ranks
+            _check_settings(args)
+            if _scan_whole_fasta_sharded(args.input_sequence, bed_path, args, report):
                 print(f"Wrote results to {bed_path}")
             return
+        entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
+        _check_settings(args)
         _scan_whole_fasta(entries, bed_path, args, report)
         print(f"Wrote results to {bed_path}")
         return

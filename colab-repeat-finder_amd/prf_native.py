@@ -371,6 +371,24 @@ class Fasta:
             pass
 
 
+def fasta_index(path):
+    """([(name, length), ...] in file order, whole).  Read from the samtools-style index `path`.fai if it lies next to an
+    uncompressed file (then `whole` is None and single records are read by seeking, Fasta(path, only=name)); otherwise the
+    file is parsed once and `whole` is the Fasta object that holds every record."""
+    fai = os.fspath(path) + ".fai"
+    if os.path.exists(fai) and not os.fspath(path).endswith(".gz"):
+        index = []
+        with open(fai) as f:
+            for line in f:
+                cols = line.rstrip("\n").split("\t")
+                if len(cols) >= 5:
+                    index.append((cols[0], int(cols[1])))
+        if index:
+            return index, None
+    whole = Fasta(path)
+    return [(e.name, len(e)) for e in whole], whole
+
+
 def scan_fasta_to_bed(ctx, fasta, bed_path, kmin, kmax, min_repeats, min_span, on_contig=None):
     """All contigs of a FASTA in ONE resident genome and one scan; BED written by libprf.  Returns rows per contig.
     on_contig(entry, n_rows) is called per contig in file order (the CLI prints the reference's lines there)."""

@@ -121,6 +121,18 @@ def test_single_record_access_with_and_without_an_index(tmp_path):
         f.writelines(line.replace("\t60\t61", "\t50\t51") for line in fai)
     for name, seq in names.items():
         assert fetch(path, name) == [(name, seq)]
+    # hostile / damaged indexes: never trusted further than the file goes, never the wrong record
+    twin = tmp_path / "twin.fa"                           # two records of the same length: an index whose offsets are swapped
+    with open(twin, "wb") as f:
+        f.write(b">a\n" + b"ACGT" * 5 + b"\n>b\n" + b"TTTT" * 5 + b"\n")
+    with open(str(twin) + ".fai", "wt") as f:
+        f.write("a\t20\t27\t20\t21\nb\t20\t3\t20\t21\n")
+    assert fetch(twin, "a") == [("a", "ACGT" * 5)] and fetch(twin, "b") == [("b", "TTTT" * 5)]
+    for bad in ("a\t20\t99999999999\t20\t21\n", "a\t18446744073709551615\t3\t20\t21\n", "a\t20\t3\t1\t4000000000\n",
+                "a\t20\t3\t0\t0\n", "a\tx\ty\n"):
+        with open(str(twin) + ".fai", "wt") as f:
+            f.write(bad)
+        assert fetch(twin, "a") == [("a", "ACGT" * 5)], bad
     gz = tmp_path / "g.fa.gz"
     with gzip.open(gz, "wb") as f:
         f.write(open(path, "rb").read())

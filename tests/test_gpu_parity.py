@@ -293,6 +293,49 @@ def test_config_c5_share_random_1250mbp_motif_1_100(ctx):
         g.free()
 
 
+def test_config_c5_as_specified_one_sequence_of_10_gbp_seed_2026(ctx):
+    """BASELINE config C5 exactly as SURVEY 8(d) specifies it: ONE sequence of 10^10 bp uniform ACGT, seed 2026, motif 1-100,
+    generated on the device, scanned on ONE GPU.  Far too long for the oracle as a whole, so: (1) size-independent properties of
+    the row set (count in the expected band, sorted, thresholds, in range, rows leave the device sorted); (2) the fused and the
+    generic kernel -- independent implementations -- agree row for row; (3) on windows at the start, in the middle (beyond
+    2^32) and at the end the oracle's rows that lie strictly inside the window equal the GPU's rows there; (4) the 8-GPU
+    sharding rehearsed on this one GPU: the eight shares of multi_gpu.plan_parts, scanned one after the other, concatenate
+    to exactly the whole scan."""
+    import multi_gpu
+    import prf_native
+    from oracle import prf_oracle
+    n, seed = 10_000_000_000, 2026
+    g = ctx.synth([n], [seed], 100)
+    try:
+        rows, stats = g.scan(1, 100, 3, 9)
+        assert stats.path == 1 and stats.positions == n and stats.sorted_on_device == 1
+        starts, ends, ks = rows["start"].astype(np.int64), rows["end"].astype(np.int64), rows["k"].astype(np.int64)
+        assert 2_000_000 < len(rows) < 2_500_000                       # SURVEY 8(d): ~210-235 rows / Mbp
+        assert np.all((starts[1:] > starts[:-1]) | ((starts[1:] == starts[:-1]) & (ends[1:] > ends[:-1])))
+        assert np.all(ends - starts >= np.maximum(3 * ks, 9)) and ends.max() <= n and ks.max() <= 100 and starts.max() > 9_990_000_000
+        rows2, stats2 = g.scan(1, 100, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert stats2.path == 0 and np.array_equal(rows, rows2)
+        del rows2
+        win, margin = 1_500_000, 1_000
+        for off in (0, 4_294_967_296 - win // 2, n - win):
+            chunk = prf_oracle.synth(win, seed, start=off)
+            want = [(s + off, e + off, k) for s, e, _m, k in prf_oracle.detect_rows(chunk, 1, 100, 3, 9)
+                    if (s >= margin or off == 0) and (e <= win - margin or off + win == n)]
+            sel = ((starts >= off + margin) | (off == 0)) & ((ends <= off + win - margin) | (off + win == n)) & (starts >= off) & (ends <= off + win)
+            got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
+            assert got == want and len(want) > 250, off
+        shares = multi_gpu.plan_parts([n], 8, prf_native.tile_positions(), [g.tile_classes(0)])
+        parts = []
+        for share in shares:
+            g.select(share)
+            r8, st8 = g.scan(1, 100, 3, 9)
+            assert st8.path == 1 and abs(int(st8.positions) - n // 8) < 2 * 65_536
+            parts.append(r8)
+        assert np.array_equal(np.concatenate(parts), rows)
+    finally:
+        g.free()
+
+
 def test_full_size_properties_translation_and_reverse_complement(ctx):
     """Size-independent properties at BASELINE C2's full size (no oracle needed, so they also run where the oracle
     would take minutes): (1) translation -- the same contig behind 12 345 + 31 leading N has the same rows, shifted;
