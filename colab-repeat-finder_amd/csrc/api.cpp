@@ -113,6 +113,11 @@ struct prf_genome {
     u64 padw = 0;        // readable words past nwords in every linear plane
     u32 kmax_hint = 0;
     u64 *H = nullptr, *L = nullptr, *X = nullptr;  // point PRF_FRONT_PAD words into their allocations
+    // symbols outside ACGTN (ordinary symbols to the reference): five planes of their codes, present only if the input has
+    // any; the tiles with such a symbol in reach (class 3) are scanned by the generic kernels
+    u64 *E[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    u64 **d_E = nullptr;                            // the five pointers, on the device (fused kernel's general routine)
+    std::vector<std::pair<u64, u64>> exotic_tiles;  // merged [first, last) ranges of class-3 tiles, ascending
     u64 *d_base = nullptr;
     uint4 *d_tile_info = nullptr;  // per tile: {contig, 0, contig base lo, hi}
     prf_vplanes vp;      // bit-sliced copy for scan_vertical
@@ -213,6 +218,9 @@ void prf_genome_free(prf_genome *g) {
     if (g->H) (void)hipFree(g->H - PRF_FRONT_PAD);
     if (g->L) (void)hipFree(g->L - PRF_FRONT_PAD);
     if (g->X) (void)hipFree(g->X - PRF_FRONT_PAD);
+    for (u64 *e : g->E)
+        if (e) (void)hipFree(e - PRF_FRONT_PAD);
+    (void)hipFree(g->d_E);
     (void)hipFree(g->d_base);
     (void)hipFree(g->d_tile_info);
     (void)hipFree(g->vp.VH);
@@ -289,7 +297,9 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     HIPCHK(hipMemsetAsync(g->L - PRF_FRONT_PAD, 0, PRF_FRONT_PAD * 8, c->stream));
     HIPCHK(hipMemsetAsync(g->X - PRF_FRONT_PAD, 0xFF, PRF_FRONT_PAD * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters, 0xFF, PRF_CNT_N * sizeof(u64), c->stream));
-    HIPCHK(prf_launch_pack_linear(c->stream, asc, g->nwords, g->H, g->L, g->X, c->d_counters + PRF_CNT_BADPOS));
+    HIPCHK(hipMemsetAsync(c->d_counters + PRF_CNT_EXOTIC, 0, sizeof(u64), c->stream));
+    HIPCHK(prf_launch_pack_linear(c->stream, asc, g->nwords, g->H, g->L, g->X, c->d_counters + PRF_CNT_BADPOS,
+                                  c->d_counters + PRF_CNT_EXOTIC));
     HIPCHK(hipMemsetAsync(g->H + g->nwords, 0, g->padw * 8, c->stream));
     HIPCHK(hipMemsetAsync(g->L + g->nwords, 0, g->padw * 8, c->stream));
     HIPCHK(hipMemsetAsync(g->X + g->nwords, 0xFF, g->padw * 8, c->stream));
@@ -318,9 +328,29 @@ static int genome_load_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs
     if (bad != ~0ull) {
         size_t ci = std::upper_bound(g->base.begin(), g->base.end(), bad) - g->base.begin() - 1;
         return fail(PRF_ESYMBOL,
-                    "unsupported symbol at contig %zu position %llu: only A,C,G,T,N (any case) can be packed; "
-                    "libprf refuses other symbols instead of guessing",
+                    "unsupported symbol at contig %zu position %llu: only letters can be packed (A, C, G, T, N and -- as ordinary "
+                    "symbols, like the reference -- any other letter, in either case); libprf refuses other bytes instead of guessing",
                     ci, (unsigned long long)(bad - g->base[ci]));
+    }
+    if (c->h_counters[PRF_CNT_EXOTIC]) {
+        // letters other than A, C, G, T, N: the planes of their codes, and the tile ranges the generic kernels take
+        for (int i = 0; i < 5; i++) {
+            u64 *p = nullptr;
+            HIPCHK(hipMalloc((void **)&p, tot * 8));
+            g->E[i] = p + PRF_FRONT_PAD;
+            HIPCHK(hipMemsetAsync(p, 0, PRF_FRONT_PAD * 8, c->stream));
+            HIPCHK(hipMemsetAsync(g->E[i] + g->nwords, 0, g->padw * 8, c->stream));
+        }
+        HIPCHK(prf_launch_pack_exotic(c->stream, asc, g->nwords, g->E));
+        HIPCHK(hipMalloc((void **)&g->d_E, 5 * sizeof(u64 *)));
+        HIPCHK(hipMemcpyAsync(g->d_E, g->E, 5 * sizeof(u64 *), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const std::vector<unsigned char> &cls = g->vp.h_class;
+        for (u64 t = 0; t + 1 < cls.size(); t++) {
+            if (cls[t] != 3) continue;
+            if (!g->exotic_tiles.empty() && g->exotic_tiles.back().second == t) g->exotic_tiles.back().second = t + 1;
+            else g->exotic_tiles.emplace_back(t, t + 1);
+        }
     }
     guard.g = nullptr;
     *out = g;
@@ -489,6 +519,7 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     prf_vscan_args a;
     a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
     a.H = g->H; a.L = g->L; a.X = g->X;
+    a.E = g->d_E;
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
     a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
     // the gather takes 8 launch slots per workgroup on small launches (more workgroups in flight), 64 on large ones
@@ -555,7 +586,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
     HIPCHK(hipSetDevice(c->dev));
 
-    prf_planes pl{g->H, g->L, g->X};
+    prf_planes pl{g->H, g->L, g->X, {g->E[0], g->E[1], g->E[2], g->E[3], g->E[4]}};
     prf_vplan plan;
     bool vs = !(flags & PRF_SCAN_FORCE_GENERIC) && prf_vertical_plan(kmin, kmax, min_repeats, min_span, &plan);
     const launch_view lv = active_launch(g);
@@ -571,7 +602,18 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         bool again = false;
         if (vs) {
             // ---- fused bit-sliced kernel (scan + verify + sorted rows per tile), then the row gather ----
-            if (lv.n == 0) {  // nothing but N (or no contig at all): no tile to launch, no rows
+            // tiles with a symbol outside ACGTN in reach are not on the launch list: the generic kernels take them below
+            std::vector<std::pair<u64, u64>> exotic;
+            if (!g->exotic_tiles.empty()) {
+                if (!g->sel_on) exotic = g->exotic_tiles;
+                else
+                    for (const auto &e : g->exotic_tiles)
+                        for (const auto &r : g->sel_tiles) {
+                            const u64 lo = std::max(e.first, r.first), hi = std::min(e.second, r.second);
+                            if (lo < hi) exotic.emplace_back(lo, hi);
+                        }
+            }
+            if (lv.n == 0 && exotic.empty()) {  // nothing but N (or no contig at all): no tile to launch, no rows
                 nhits = ncand = 0;
                 launches = 0;
                 sorted_on_device = true;
@@ -581,6 +623,13 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 }
                 break;
             }
+            if (lv.n == 0) {  // only such tiles: no fused launch
+                int rc0 = ensure_buffers(c, want_cand, want_hits);
+                if (rc0) return rc0;
+                nhits = ncand = 0;
+                launches = 0;
+                sorted_on_device = true;
+            } else {
             int rc = ensure_slabs(c, lv.n, slab_cap);
             if (rc) return rc;
             rc = ensure_buffers(c, c->cand_cap, want_hits);  // the compact row array
@@ -637,6 +686,46 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             if (!again && !c->sink && nhits > c->hit_cap) {  // the compact row array was too small: grow it and scan again
                 want_hits = nhits + nhits / 8 + 1024;
                 again = true;
+            }
+            }  // fused launch
+            if (!again && !exotic.empty()) {
+                // ---- tiles with symbols outside ACGTN in reach: generic kernels with the symbols' own planes (R == R matches,
+                // reference utils/perfect_repeat_tracker.py:53); a row belongs to the tile of its first position there too, so
+                // the two row sets are disjoint.  The rows are appended; the array is then sorted on the host.
+                int rc = ensure_buffers(c, want_cand, c->hit_cap);
+                if (rc) return rc;
+                prf_hit_dev *rows_base = c->sink ? c->sink : c->d_hits;
+                const u64 rows_cap = c->sink ? c->sink_cap : c->hit_cap;
+                const u64 room = rows_cap > nhits ? rows_cap - nhits : 0;
+                HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+                for (const auto &tr : exotic)
+                    HIPCHK(prf_launch_scan_generic(c->stream, pl, tr.first * PRF_TILE_WORDS, tr.second * PRF_TILE_WORDS, kmin, kmax,
+                                                   min_repeats, min_span, c->d_cand, c->cand_cap, c->d_counters));
+                HIPCHK(prf_launch_verify(c->stream, pl, c->d_cand, c->cand_cap, min_repeats, min_span, g->d_base, (u32)g->base.size(),
+                                         rows_base + nhits, room, c->d_counters));
+                u64 *stage = c->h_counters + PRF_CNT_N + 2;  // spare pinned words behind the counter block
+                HIPCHK(hipMemcpyAsync(stage, c->d_counters, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                const u64 ncand_g = stage[PRF_CNT_CAND], nhits_g = stage[PRF_CNT_HITS];
+                launches += 1 + (u32)exotic.size();
+                if (ncand_g > c->cand_cap) { want_cand = ncand_g + ncand_g / 8 + 1024; again = true; }
+                if (!again && nhits_g > room) {
+                    if (c->sink)
+                        return fail(PRF_EINVAL, "the row sink holds %llu rows, the scan found %llu", (unsigned long long)c->sink_cap,
+                                    (unsigned long long)(nhits + nhits_g));
+                    want_hits = nhits + nhits_g + (nhits + nhits_g) / 8 + 1024;
+                    again = true;
+                }
+                if (!again) {
+                    ncand += ncand_g;
+                    nhits += nhits_g;
+                    if (nhits_g) sorted_on_device = false;
+                    if (c->sink) {  // the count record behind a caller-owned row array
+                        stage[0] = nhits; stage[1] = 0; stage[2] = 0;
+                        HIPCHK(hipMemcpyAsync(c->sink + c->sink_cap, stage, sizeof(prf_hit_dev), hipMemcpyHostToDevice, c->stream));
+                        HIPCHK(hipStreamSynchronize(c->stream));
+                    }
+                }
             }
         } else {
             // ---- generic path: candidates, then rows ----
@@ -760,6 +849,8 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
         return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: no fused plan for these parameters");
     const launch_view lv = active_launch(g);
     if (lv.n == 0) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: nothing to launch");
+    if (!g->exotic_tiles.empty())
+        return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: the genome holds symbols outside ACGTN (a second pass follows the fused scan); scan synchronously");
     if (lv.n > c->slab_slots || c->slab_cap == 0 || c->hit_cap == 0)
         return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: scan this genome synchronously once first (buffers are sized there)");
     HIPCHK(hipSetDevice(c->dev));

@@ -7,13 +7,16 @@
 #include "prf_host.h"
 
 // One thread packs one 64-position word: 64 bytes in (4 x 16-B loads), 3 x 8 bytes out.
+// Symbols: A, C, G, T -> code; N -> X; any other LETTER is an ordinary symbol to the reference (R == R matches,
+// utils/perfect_repeat_tracker.py:53): X is set for it here and *exotic is raised, so that the planes of its code are built
+// (prf_pack_exotic_kernel); a byte that is no letter at all is refused (bad_pos).
 __global__ __launch_bounds__(256) void prf_pack_linear_kernel(const uint8_t *__restrict__ asc, u64 nwords,
                                                               u64 *__restrict__ H, u64 *__restrict__ L,
-                                                              u64 *__restrict__ X, u64 *__restrict__ bad_pos) {
+                                                              u64 *__restrict__ X, u64 *__restrict__ bad_pos, u64 *__restrict__ exotic) {
     const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     const uint4 *src = reinterpret_cast<const uint4 *>(asc + w * 64);
-    u64 h = 0, l = 0, x = 0, bad = 0;
+    u64 h = 0, l = 0, x = 0, bad = 0, exo = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint4 v = src[q];
@@ -29,11 +32,13 @@ __global__ __launch_bounds__(256) void prf_pack_linear_kernel(const uint8_t *__r
                 // bytes outside both letter ranges can never equal 'A','C','G','T','N' after the fold
                 // except 0x41..0x5A themselves.
                 const u32 is_n = (f == 'N');
+                const u32 is_letter = (f >= 'A') & (f <= 'Z');
                 const int bit = q * 16 + j * 4 + b;
                 h |= (u64)((f >> 2) & 1u & is_acgt) << bit;
                 l |= (u64)((f >> 1) & 1u & is_acgt) << bit;
                 x |= (u64)(is_acgt ^ 1u) << bit;
-                bad |= (u64)((is_acgt | is_n) ^ 1u) << bit;
+                bad |= (u64)(is_letter ^ 1u) << bit;
+                exo |= (u64)(is_letter & ((is_acgt | is_n) ^ 1u)) << bit;
             }
         }
     }
@@ -41,6 +46,42 @@ __global__ __launch_bounds__(256) void prf_pack_linear_kernel(const uint8_t *__r
     L[w] = l;
     X[w] = x;
     if (bad) atomicMin(bad_pos, w * 64 + (u64)__builtin_ctzll(bad));
+    if (exo) atomicMax(exotic, 1ull);
+}
+
+// the five code planes of the symbols outside ACGTN (prf_planes::E): low five bits of the upper-cased letter
+__global__ __launch_bounds__(256) void prf_pack_exotic_kernel(const uint8_t *__restrict__ asc, u64 nwords, u64 *__restrict__ E0,
+                                                              u64 *__restrict__ E1, u64 *__restrict__ E2, u64 *__restrict__ E3,
+                                                              u64 *__restrict__ E4) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(asc + w * 64);
+    u64 e[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = src[q];
+        const u32 d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u32 f = ((d[j] >> (8 * b)) & 0xFFu) & 0xDFu;
+                const u32 plain = (f == 'A') | (f == 'C') | (f == 'G') | (f == 'T') | (f == 'N');
+                const u32 code = ((f >= 'A') & (f <= 'Z') & (plain ^ 1u)) ? (f & 31u) : 0u;
+                const int bit = q * 16 + j * 4 + b;
+#pragma unroll
+                for (int i = 0; i < 5; i++) e[i] |= (u64)((code >> i) & 1u) << bit;
+            }
+        }
+    }
+    E0[w] = e[0]; E1[w] = e[1]; E2[w] = e[2]; E3[w] = e[3]; E4[w] = e[4];
+}
+
+hipError_t prf_launch_pack_exotic(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *const *E) {
+    const u32 bs = 256;
+    const u64 nb = (nwords + bs - 1) / bs;
+    hipLaunchKernelGGL(prf_pack_exotic_kernel, dim3((u32)nb), dim3(bs), 0, s, asc, nwords, E[0], E[1], E[2], E[3], E[4]);
+    return hipGetLastError();
 }
 
 // fill value for guard gaps and padding: N
@@ -163,10 +204,10 @@ hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed) {
 }
 
 hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
-                                  u64 *bad_pos) {
+                                  u64 *bad_pos, u64 *exotic) {
     const u32 bs = 256;
     const u64 nb = (nwords + bs - 1) / bs;
-    hipLaunchKernelGGL(prf_pack_linear_kernel, dim3((u32)nb), dim3(bs), 0, s, asc, nwords, H, L, X, bad_pos);
+    hipLaunchKernelGGL(prf_pack_linear_kernel, dim3((u32)nb), dim3(bs), 0, s, asc, nwords, H, L, X, bad_pos, exotic);
     return hipGetLastError();
 }
 

@@ -37,6 +37,11 @@ struct prf_hit_dev {
 
 struct prf_planes {
     const u64 *H, *L, *X;
+    // Symbols other than A, C, G, T, N (IUPAC codes ...) are ORDINARY symbols to the reference: R == R matches, only the
+    // literal N never does (utils/perfect_repeat_tracker.py:53).  They are rare, so they do not get planes of their own on the
+    // fast path: X is set for them (like N), and five extra linear planes E[0..4] hold the low five bits of the upper-cased
+    // letter (A = 1 ... Z = 26; 0 for A, C, G, T and N).  E[0] == nullptr: the genome holds no such symbol.
+    const u64 *E[5];
 };
 
 // funnel shift right of the 128-bit value hi:lo by s in [0,63]
@@ -50,12 +55,27 @@ __device__ __forceinline__ u64 prf_bits_at(const u64 *__restrict__ P, u64 q) {
     return prf_fsr(P[w], P[w + 1], (unsigned)(q & 63));
 }
 
+// bits j = q .. q+63 at which seq[j] and seq[j+k] are both symbols outside ACGTN and equal
+__device__ __forceinline__ u64 prf_exotic_equal64(const u64 *const *E, u64 q, u32 k) {
+    u64 nz_a = 0, nz_b = 0, diff = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const u64 a = prf_bits_at(E[i], q), b = prf_bits_at(E[i], q + k);
+        nz_a |= a;
+        nz_b |= b;
+        diff |= a ^ b;
+    }
+    return nz_a & nz_b & ~diff;
+}
+
 // mismatch bits (1 = "seq[j] != seq[j+k] or seq[j] is N or seq[j+k] is N") for j = q .. q+63
 __device__ __forceinline__ u64 prf_mismatch64(const prf_planes &p, u64 q, u32 k) {
     const u64 h = prf_bits_at(p.H, q) ^ prf_bits_at(p.H, q + k);
     const u64 l = prf_bits_at(p.L, q) ^ prf_bits_at(p.L, q + k);
     const u64 x = prf_bits_at(p.X, q) | prf_bits_at(p.X, q + k);
-    return h | l | x;
+    u64 m = h | l | x;
+    if (p.E[0] && x) m &= ~prf_exotic_equal64(p.E, q, k);  // both sides the same symbol outside ACGTN: a match
+    return m;
 }
 
 // minimum number of consecutive matching positions of a reportable run:

@@ -8,7 +8,8 @@
 enum {
     PRF_CNT_CAND = 0,      // generic path: phase-1 candidates
     PRF_CNT_HITS = 1,      // generic path: rows
-    PRF_CNT_BADPOS = 2,    // packer: first unsupported symbol
+    PRF_CNT_BADPOS = 2,    // packer: first byte that is not a letter
+    PRF_CNT_EXOTIC = 7,    // packer: 1 = the input holds letters other than A, C, G, T, N
     PRF_CNT_UNSORTED = 3,  // fused path: a tile wrote rows past its LDS sort list -> the row array is not fully sorted
     PRF_CNT_HIT_OVF = 4,   // fused path: largest per-tile row demand above the slab capacity
     PRF_CNT_ROWS = 5,      // fused path: rows in the compact array (written by the gather kernel)
@@ -21,7 +22,8 @@ enum {
 };
 
 hipError_t prf_launch_pack_linear(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *H, u64 *L, u64 *X,
-                                  u64 *bad_pos);
+                                  u64 *bad_pos, u64 *exotic);
+hipError_t prf_launch_pack_exotic(hipStream_t s, const uint8_t *asc, u64 nwords, u64 *const *E);
 hipError_t prf_launch_fill_u64(hipStream_t s, u64 *p, u64 n, u64 v);
 hipError_t prf_launch_synth(hipStream_t s, uint8_t *asc, u64 n, u64 seed);
 // stand-in recipe 2 (synth.py::standin2): background + N blocks + one planted repeat per 588-position slot

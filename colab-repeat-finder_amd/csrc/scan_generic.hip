@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void prf_scan_generic_kernel(prf_planes pl, u6
     for (u64 w = w_begin + (u64)blockIdx.x * blockDim.x + threadIdx.x; w < w_end; w += stride) {
         const u64 xa = pl.X[w];
         // a word of nothing but N / guard gap cannot start a run
-        if (xa == ~0ull) continue;
+        if (xa == ~0ull && !pl.E[0]) continue;
         const u64 ha = pl.H[w], hb = pl.H[w + 1];
         const u64 la = pl.L[w], lb = pl.L[w + 1];
         const u64 xb = pl.X[w + 1];
@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void prf_scan_generic_kernel(prf_planes pl, u6
                 const u64 hq = pl.H[q - 1], lq = pl.L[q - 1], xq = pl.X[q - 1];
                 const u64 mp = (hp ^ prf_fsr(hq, h0, s)) | (lp ^ prf_fsr(lq, l0, s)) | xp | prf_fsr(xq, x0, s);
                 mprev = mp >> 63;
+            }
+            if (pl.E[0]) {  // the genome holds symbols outside ACGTN: equal ones match (prf_planes::E)
+                m.lo &= ~prf_exotic_equal64(pl.E, w * 64, k);
+                m.hi &= ~prf_exotic_equal64(pl.E, w * 64 + 64, k);
+                if (w && mprev) mprev = (prf_exotic_equal64(pl.E, w * 64 - 64, k) >> 63) ^ 1ull;
             }
             const long long M = prf_min_matches(k, min_repeats, min_span);
             const unsigned mcap = (unsigned)(M < 1 ? 1 : (M > 64 ? 64 : M));

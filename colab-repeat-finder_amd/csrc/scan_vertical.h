@@ -16,7 +16,8 @@
 // Bit-sliced planes: see scan_vertical.hip for the layout.
 struct prf_vplanes {
     u32 *VH = nullptr, *VL = nullptr, *VX = nullptr;
-    unsigned char *tile_class = nullptr;  // per tile: 0 clean, 1 has not-ACGT positions in reach, 2 nothing but not-ACGT
+    unsigned char *tile_class = nullptr;  // per tile: 0 clean, 1 has not-ACGT positions in reach, 2 nothing but not-ACGT,
+                                          // 3 a symbol outside ACGTN in reach (generic kernels)
     u32 *launch_list = nullptr;           // device: the tiles to scan in position order, PRF_LAUNCH_MIXED set on class-1 tiles
     u32 n_launch = 0;
     u32 flat_base = ~0u;                  // first tile if the list is one contiguous range of clean tiles
@@ -56,6 +57,7 @@ struct prf_vplan {
 struct prf_vscan_args {
     const u32 *VH, *VL, *VX;       // bit-sliced planes
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
+    const u64 *const *E;           // device array of the five planes of the symbols outside ACGTN, or nullptr
     const u32 *launch_list;        // tiles in position order (PRF_LAUNCH_MIXED flags); one workgroup per entry
     u32 n_launch;
     u32 flat_base;                 // != ~0u: entry i is the clean tile flat_base + i (no dependent load)

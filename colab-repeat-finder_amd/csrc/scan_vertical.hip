@@ -106,6 +106,7 @@ struct TileCtx {
     u64 w0;                   // first word of the linear window
     u64 xz_lo, xz_hi;         // positions known to hold no not-ACGT symbol
     const u64 *H, *L, *X;     // linear planes in HBM
+    const u64 *const *E;      // device array of the five planes of the symbols outside ACGTN, or nullptr (prf_planes::E)
     prf_hit_dev *slab;        // this tile's row slab in HBM
     u64 contig_base;          // a tile lies inside one contig
     u64 tile_base;            // first position of the tile
@@ -191,6 +192,7 @@ __device__ __noinline__ u64 tile_mismatch64(u64 q, u32 k) {
     view.xz_hi = tc.xz_hi;
     view.x_in_lds = 0;
     view.P[0] = tc.H; view.P[1] = tc.L; view.P[2] = tc.X;
+    view.E = tc.E;
     return view.mismatch64(q, k);
 }
 
@@ -1014,6 +1016,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             tc.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
             tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
             tc.H = g.H; tc.L = g.L; tc.X = g.X;
+            tc.E = g.E;
             tc.slab = g.slabs + (u64)slot * g.slab_cap;
             tc.contig = info.x;
             tc.contig_base = (u64)info.z | ((u64)info.w << 32);
@@ -1281,6 +1284,7 @@ __global__ __launch_bounds__(64) void prf_pack_vertical_kernel(const uint8_t *__
     const u64 tile = blockIdx.x;
     const int lane = (int)threadIdx.x;
     u32 h[T], l[T], x[T];
+    u32 exo = 0;  // any letter other than A, C, G, T, N
 #pragma unroll
     for (int t = 0; t < T; t++) h[t] = l[t] = x[t] = 0;
     const uint8_t *base = asc + tile * PRF_TILE + (u64)lane * T;
@@ -1295,6 +1299,7 @@ __global__ __launch_bounds__(64) void prf_pack_vertical_kernel(const uint8_t *__
             h[t] |= ((f >> 2) & 1u & ok) << b;
             l[t] |= ((f >> 1) & 1u & ok) << b;
             x[t] |= (ok ^ 1u) << b;
+            exo |= (ok | (f == 'N')) ^ 1u;
         }
     }
     u32 any = 0, all = ~0u;
@@ -1314,17 +1319,20 @@ __global__ __launch_bounds__(64) void prf_pack_vertical_kernel(const uint8_t *__
     }
     const bool w_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
     const bool w_all = __builtin_amdgcn_ballot_w64(all != ~0u) == 0;
-    if (lane == 0) any_all[tile] = (unsigned char)((w_any ? 1 : 0) | (w_all ? 2 : 0));
+    const bool w_exo = __builtin_amdgcn_ballot_w64(exo != 0) != 0;
+    if (lane == 0) any_all[tile] = (unsigned char)((w_any ? 1 : 0) | (w_all ? 2 : 0) | (w_exo ? 4 : 0));
 }
 
-// class: 2 = only not-ACGT, 1 = some not-ACGT in this tile or the next (whose first lanes are this tile's
-// virtual lanes 64..), 0 = clean
+// class: 3 = a symbol outside ACGTN in this tile, the one before or the one after (such tiles are scanned by the generic
+// kernels, with the symbols' own planes); 2 = only not-ACGT; 1 = some not-ACGT in this tile or the next (whose first lanes
+// are this tile's virtual lanes 64..); 0 = clean
 __global__ void prf_tile_class_kernel(const unsigned char *__restrict__ any_all, unsigned char *__restrict__ cls, u64 ntiles) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntiles) return;
     const unsigned char a = any_all[i];
     const unsigned char b = (i + 1 < ntiles) ? any_all[i + 1] : (unsigned char)3;
-    cls[i] = (a & 2) ? 2 : (((a | b) & 1) ? 1 : 0);
+    const unsigned char p = i ? any_all[i - 1] : (unsigned char)0;
+    cls[i] = ((a | b | p) & 4) ? 3 : ((a & 2) ? 2 : (((a | b) & 1) ? 1 : 0));
 }
 
 }  // namespace

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void prf_verify_kernel(prf_planes pl, const u6
     if (n > cand_cap) n = cand_cap;  // overflow is reported to the host, which re-runs with a larger buffer
     prf_global_view view;
     view.P[0] = pl.H; view.P[1] = pl.L; view.P[2] = pl.X;
+    for (int i = 0; i < 5; i++) view.E[i] = pl.E[i];
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const u64 rec = cand[i];

@@ -16,13 +16,16 @@
 
 struct prf_global_view {
     const u64 *P[3];
+    const u64 *E[5];  // planes of the symbols outside ACGTN (prf_planes::E); E[0] == nullptr: none
     __device__ __forceinline__ u64 bits(int plane, u64 q) const { return prf_bits_at(P[plane], q); }
-    // mismatch bits (1 = differs, or either side is not ACGT) of positions q .. q+63 against q+k ..
+    // mismatch bits (1 = differs, or either side is N) of positions q .. q+63 against q+k ..
     __device__ __forceinline__ u64 mismatch64(u64 q, u32 k) const {
         const u64 h = bits(0, q) ^ bits(0, q + k);
         const u64 l = bits(1, q) ^ bits(1, q + k);
         const u64 x = bits(2, q) | bits(2, q + k);
-        return h | l | x;
+        u64 m = h | l | x;
+        if (E[0] && x) m &= ~prf_exotic_equal64(E, q, k);
+        return m;
     }
 };
 
@@ -38,6 +41,7 @@ struct prf_window_view {
     u64 xz_lo, xz_hi;
     u32 x_in_lds;  // 1: the window also holds the X plane (third), used by tiles with N in reach
     const u64 *P[3];
+    const u64 *const *E;  // device array of the five planes of the symbols outside ACGTN, or nullptr (prf_planes::E)
     __device__ __forceinline__ u64 bits(int plane, u64 q) const {
         if (plane == 2 && !x_in_lds) {
             if (q >= xz_lo && q + 64 <= xz_hi) return 0;
@@ -63,7 +67,9 @@ struct prf_window_view {
         const u64 h = bits(0, q) ^ bits(0, q + k);
         const u64 l = bits(1, q) ^ bits(1, q + k);
         const u64 x = bits(2, q) | bits(2, q + k);
-        return h | l | x;
+        u64 m = h | l | x;
+        if (E && x) m &= ~prf_exotic_equal64(E, q, k);  // (a window or a tile with such a symbol in reach is never scanned here)
+        return m;
     }
 };
 

@@ -24,7 +24,8 @@ def plan_contig_shards(lengths, world):
     return [sorted(s) for s in shards]
 
 
-TILE_COST = (1.0, 1.6, 0.0)   # ordinary tile, tile with not-ACGT symbols in reach (three planes, verified on the global planes), all-N tile
+TILE_COST = (1.0, 1.3, 0.0, 12.0)   # ordinary tile; tile with N in reach (three planes); all-N tile (never scanned); tile with a
+                                   # symbol outside ACGTN in reach (generic kernels: an order of magnitude slower)
 
 
 def plan_parts(lengths, world, tile, classes=None):

@@ -43,7 +43,7 @@ def _to_ascii(seq):
         return seq.encode("ascii")
     except UnicodeEncodeError as exc:
         raise ValueError(f"input_sequence contains a non-ASCII character at offset {exc.start}; "
-                         "the packed GPU path accepts A,C,G,T,N in either case") from None
+                         "the packed GPU path accepts letters only (A, C, G, T, N and, as ordinary symbols, any other letter)") from None
 
 
 def _gpu_rows(seq, fs, context=None):

@@ -13,7 +13,8 @@ Fixture files (all under tests/golden/):
   ref_unit_tests.json     the reference's own known-answer vectors
                           (perfect_repeat_finder_tests.py:21-143), re-run here
   fuzz_small.jsonl.gz     random small cases incl. interval mode / min_repeats=1 / exceptions
-  adversarial.jsonl.gz    tile/word-boundary, all-A, all-N, k > L, IUPAC, lowercase ...
+  adversarial.jsonl.gz    tile/word-boundary, all-A, all-N, k > L, lowercase ...
+  iupac.jsonl.gz          symbols other than ACGTN (ordinary symbols to the reference), incl. at tile edges
   synth_*.json            SURVEY 8(d) synthetic sequences (by seed/length) + reference rows
   chr22_clusters.tsv.gz   known-answer clusters mined from the reference's golden BED
                           (benchmark/repeat_finder/chr22_repeats.bed), each re-run through the reference
@@ -209,6 +210,64 @@ def gen_adversarial():
     print("adversarial:", len(cases))
 
 
+def gen_iupac():
+    """Symbols other than A, C, G, T, N are ORDINARY symbols to the reference: R == R matches, R != A does not, only the
+    literal N never matches (utils/perfect_repeat_tracker.py:53, :83); .upper() folds case (perfect_repeat_finder.py:33).
+    Cases: hand-made ones, random sequences over a mixed alphabet with planted repeats whose motifs hold IUPAC letters,
+    and long ones with such repeats at and across the 65536-base tile edges of the GPU design (kept short in k to bound
+    the reference's run time)."""
+    rng = random.Random(11)
+    cases = []
+
+    def add(tag, seq, st):
+        cases.append({"tag": tag, "seq": seq, "settings": st, **run_ref(seq, st)})
+
+    add("R_run", "ACGT" + "R" * 12 + "ACGT", ns(1, 6, 3, 9))
+    add("R_vs_N", "R" * 10 + "N" * 10 + "R" * 10, ns(1, 6, 3, 9))
+    add("motif_with_Y", "GATTACA" + "ACY" * 7 + "TTGCA", ns(1, 10, 3, 9))
+    add("motif_all_iupac", "ACGT" * 3 + "RYKM" * 6 + "ACGT" * 3, ns(1, 12, 3, 9))
+    add("lowercase_iupac", "acgt" + "ryRYry" * 4 + "wsWS" * 5 + "n" * 4 + "acg", ns(1, 8, 3, 9))
+    add("iupac_breaks_a_run", "CA" * 6 + "R" + "CA" * 6, ns(1, 6, 3, 9))
+    add("iupac_next_to_N", "CAG" * 5 + "N" + "RAG" * 5 + "NRNRNRNRNRNR", ns(1, 6, 3, 9))
+    add("every_letter", "".join(chr(c) * 11 for c in range(ord("A"), ord("Z") + 1)), ns(1, 4, 3, 9))
+    add("non_primitive_iupac", "RR" * 10 + "A" + "RYRY" * 6, ns(1, 8, 3, 9))
+    add("interval_iupac", "GATGG" + "RYR" * 9 + "ACAGTTTTTTTTTT", ns(1, 20, 3, 3, interval=(5, 20)))
+    alpha = "ACGTACGTACGTRYKMSWBDHVN"
+    for i in range(260):
+        n = rng.choice([30, 80, 200, 600])
+        seq = list(rand_seq(rng, n, alpha if i % 3 else "ACGTRYN"))
+        for _ in range(rng.randint(0, 4)):
+            k = rng.choice([1, 1, 2, 3, 4, 5, 7, 9, 12])
+            motif = rand_seq(rng, k, "ACGTRYKMSW")
+            copies = rng.choice([2, 3, 3, 4, 6, 9])
+            p = rng.randrange(max(1, n - 1))
+            body = (motif * copies + motif[:rng.randrange(k)])[:max(0, n - p)]
+            seq[p:p + len(body)] = body
+        seq = "".join(seq)
+        if i % 5 == 0:
+            seq = "".join(c.lower() if rng.random() < 0.4 else c for c in seq)
+        add(f"rand{i}", seq, ns(rng.choice([1, 1, 2]), rng.choice([6, 12, 20]), rng.choice([2, 3, 3, 4]), rng.choice([1, 6, 9, 14])))
+    # around the 65536-base tile edges: IUPAC motifs ending before / starting at / crossing the edge, a lone IUPAC letter in
+    # the last and first positions of a tile, a plain repeat next to one
+    for j, (motif, where) in enumerate((("R", -5), ("AY", -21), ("ACR", 0), ("ACGTR", -1), ("KM", -65), ("CAG", -40), ("WSW", 3))):
+        pre = list(rand_seq(rng, 65536 + 400, "ACGT"))
+        p = 65536 + where
+        body = (motif * 30)[:48]
+        pre[p - 1] = "C" if body[0] != "C" else "A"
+        pre[p:p + len(body)] = body
+        pre[p + len(body)] = "G" if body[-1] != "G" else "T"
+        if motif == "CAG":
+            pre[65535] = "R"
+            pre[65536] = "Y"
+        add(f"tile_edge_iupac_{j}_{motif}", "".join(pre), ns(1, 6, 3, 9))
+    path = os.path.join(OUT, "iupac.jsonl.gz")
+    with gzip.open(path, "wt") as f:
+        for c in cases:
+            f.write(json.dumps(c) + "\n")
+    ok = sum(1 for c in cases if c["status"] == "ok")
+    print("iupac:", len(cases), "cases,", ok, "ok,", sum(len(c.get("rows") or []) for c in cases), "rows")
+
+
 def gen_synth(quick):
     specs = [(200_000, 22, ns(2, 6, 3, 9)), (200_000, 22, ns(1, 50, 3, 9))]
     if not quick:
@@ -291,13 +350,15 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "clusters", "synth"]
+    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "iupac", "clusters", "synth"]
     if "unit" in todo:
         gen_ref_unit_tests()
     if "fuzz" in todo:
         gen_fuzz_small(600 if a.quick else 4000)
     if "adv" in todo:
         gen_adversarial()
+    if "iupac" in todo:
+        gen_iupac()
     if "clusters" in todo:
         gen_chr22_clusters(1500 if a.quick else 8000)
     if "synth" in todo:

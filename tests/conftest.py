@@ -53,6 +53,11 @@ def golden_adversarial():
 
 
 @pytest.fixture(scope="session")
+def golden_iupac():
+    return load_jsonl_gz("iupac.jsonl.gz")
+
+
+@pytest.fixture(scope="session")
 def golden_unit():
     return load_json("ref_unit_tests.json")["cases"]
 

@@ -181,6 +181,70 @@ def test_widest_lds_image_with_n_blocks_kmax_260_to_480(ctx):
         g.free()
 
 
+def test_symbols_other_than_acgtn_are_ordinary_symbols(ctx, detect, golden_iupac):
+    """The reference compares characters: R == R matches, R != A does not, only the literal N never matches
+    (utils/perfect_repeat_tracker.py:53, :83).  (1) The reference's own outputs on 277 sequences with IUPAC letters
+    (tests/golden/iupac.jsonl.gz).  (2) A multi-contig genome with such letters sprinkled in -- single ones, runs, repeats whose
+    motifs hold them, at tile edges, next to N blocks -- on the fused path (tiles with such a symbol in reach go to the generic
+    kernels, the rest stays on the fused kernel), on the forced generic path, and cut into shares: all equal the oracle."""
+    import multi_gpu
+    import prf_native
+    import synth
+    for case in golden_iupac:
+        assert outcome(detect, case["seq"], case["settings"]) == expected(case), case["tag"]
+    rng = np.random.default_rng(8)
+    seqs = []
+    for ci, n in enumerate((3_500_000, 70_000, 300_000)):
+        s = bytearray(synth.standin2(n, 90 + ci).tobytes())
+        for _ in range(12 if ci != 2 else 0):                        # contig 2 stays plain: whole contigs without such symbols
+            p = int(rng.integers(20_000, n - 5_000))
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                s[p] = ord("R")
+            elif kind == 1:
+                s[p:p + 30] = b"Y" * 30
+            elif kind == 2:
+                s[p:p + 60] = (b"ACR" * 20)
+            elif kind == 3:
+                s[p:p + 90] = (b"GATTAKMCW" * 10)
+            else:
+                s[p:p + 40] = b"wsWS" * 10
+        if ci == 0:
+            for edge in (65_536, 131_072, 196_608, 10 * 65_536):     # at and across tile edges; next to an N block
+                s[edge - 7:edge + 8] = b"RY" * 7 + b"R"
+            s[3 * 65_536 + 100:3 * 65_536 + 130] = b"N" * 30
+            s[3 * 65_536 + 130:3 * 65_536 + 190] = b"AYG" * 20
+            s[5 * 65_536 - 1] = ord("K")
+            s[7 * 65_536] = ord("M")
+            s[8 * 65_536 - 40:8 * 65_536 + 40] = b"CAGR" * 20
+        seqs.append(bytes(s))
+    want = [(c, a, b, k) for c, s in enumerate(seqs) for a, b, k in oracle_rows(s, 1, 50, 3, 9)]
+    g = ctx.load(seqs, 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.sorted_on_device == 0            # two row sets (fused tiles, generic tiles): merged on the host
+        assert rows_as_tuples(rows) == want
+        assert any(b"R"[0] in seqs[c][a:a + k].upper() or b"Y"[0] in seqs[c][a:a + k].upper() for c, a, _b, k in want)
+        cls0 = g.tile_classes(0)
+        assert 3 in cls0 and 0 in cls0 and 3 not in g.tile_classes(2)
+        rows2, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert st2.path == 0 and rows_as_tuples(rows2) == want
+        for world in (2, 5):
+            shares = multi_gpu.plan_parts([len(s) for s in seqs], world, prf_native.tile_positions(),
+                                          [g.tile_classes(c) for c in range(len(seqs))])
+            got = []
+            for share in shares:
+                g.select(share)
+                r, _ = g.scan(1, 50, 3, 9)
+                got += rows_as_tuples(r)
+            assert got == want, world
+        g.select(None)
+        with pytest.raises(prf_native.PrfError):
+            g.scan_async(1, 50, 3, 9)                               # the pipelined call has no second pass: refused, not wrong
+    finally:
+        g.free()
+
+
 def test_very_long_runs_flush_the_candidate_lists(ctx):
     """An all-A contig is one run for every k: every stream start inside it is a (spurious) candidate, the
     per-wave candidate lists of the fused kernel fill up over and over and are verified on the spot; the
@@ -210,8 +274,10 @@ def test_row_slab_overflow_grows_the_slabs(ctx):
 def test_errors_cross_the_boundary_cleanly(ctx):
     import prf_native
     with pytest.raises(prf_native.PrfError) as info:
-        ctx.scan([b"ACGTRYACGT"], 1, 5, 3, 9)
+        ctx.scan([b"ACGT-*ACGT"], 1, 5, 3, 9)                # letters only: anything else is refused, never guessed
     assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
+    rows, _ = ctx.scan([b"ACGTRYACGT"], 1, 5, 3, 9)          # IUPAC letters are ordinary symbols (see the test below)
+    assert len(rows) == 0
     with pytest.raises(prf_native.PrfError) as info:
         ctx.scan([b"ACGT"], 1, 5, 1, 9)
     assert info.value.code == prf_native.PRF_EUNSUPPORTED

@@ -29,6 +29,13 @@ def test_adversarial(golden_adversarial):
         assert outcome(prf_oracle.detect_repeats, case["seq"], case["settings"]) == expected(case), case["tag"]
 
 
+def test_symbols_other_than_acgtn_are_ordinary_symbols(golden_iupac):
+    """iupac.jsonl.gz: the reference run on sequences with IUPAC letters (R == R matches, only N never does)."""
+    assert len(golden_iupac) >= 270 and sum(len(c.get("rows") or []) for c in golden_iupac) > 2500
+    for case in golden_iupac:
+        assert outcome(prf_oracle.detect_repeats, case["seq"], case["settings"]) == expected(case), case["tag"]
+
+
 def test_chr22_clusters(golden_clusters):
     st = dict(min_motif_size=1, max_motif_size=6, min_repeats=3, min_span=9)
     assert len(golden_clusters) >= 8000
