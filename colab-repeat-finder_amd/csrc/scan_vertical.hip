@@ -57,6 +57,7 @@ constexpr int REC_PER_WAVE = 96;                              // group-task cand
 constexpr int MAX_WAVES = PRF_VMAX_WAVES;
 constexpr int NTH = 64 * MAX_WAVES;                           // threads per workgroup, always
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
+constexpr u32 FLAGS_PER_TASK = 128;                           // flags (lane, stream) an exact task's list holds: 256 B per task
 constexpr int ROW_CAP_LDS = 256;                              // rows of a tile sorted in LDS (more: unsorted, host sorts)
 
 template <int A, class F, int... I>
@@ -529,75 +530,37 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
     wc.win0 = tc.tile_base - 64;
     wc.min_repeats = tc.min_repeats;
     wc.min_span = tc.min_span;
-    // ---- exact tasks: one word per (task, lane) lies in LDS.  Every thread collects the flags of its lane's streams in its
-    // quarter of the words, the flags are dealt to the threads one by one through a list (lies where the image was, behind
-    // the row list): a wave then runs the body about once, not as often as its unluckiest lane has flags.
+    // ---- exact tasks: every task left a ballot-compacted list of its flags (lane, stream bit) in LDS (Emit::push_flags).
+    // The flags of all tasks are one index space, dealt to the threads one by one: a wave runs the body about once, not as
+    // often as its unluckiest lane has flags.
     u32 n_flags = 0;
     if (tc.n_exact) {
         constexpr u32 MAX_EXACT = SMALL_M - 1;  // motif sizes 1 .. 14 at most
-        constexpr u32 FLAG_CAP_WAVE = 512;
-        typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
-        prf_lds_u16 *flags = (prf_lds_u16 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 16);  // 4 lists of FLAG_CAP_WAVE
-        prf_lds_u32 *flag_cnt = (prf_lds_u32 *)(prf_smem + 172);                         // [MAX_WAVES]
-        prf_lds_cu32 *hotw = (prf_lds_cu32 *)(prf_smem + tc.hotw_off);
-        const u32 n_exact = tc.n_exact, rl = tid & 63u;
-        u32 hw[MAX_EXACT];
-        static_for<0, (int)MAX_EXACT>([&](auto ec) {  // all reads in flight at once (words past the last task are other data: masked)
+        typedef __attribute__((address_space(3))) const unsigned short prf_lds_cu16;
+        prf_lds_cu16 *lists = (prf_lds_cu16 *)(prf_smem + tc.hotw_off);
+        prf_lds_cu32 *counts = (prf_lds_cu32 *)(prf_smem + tc.hotw_off) + tc.n_exact * 64u;
+        u32 pre[MAX_EXACT + 1];
+        pre[0] = 0;
+        static_for<0, (int)MAX_EXACT>([&](auto ec) {  // (words past the last task are other data: masked)
             constexpr u32 e = (u32)decltype(ec)::value;
-            hw[e] = hotw[e * 64u + rl];
+            const u32 c = counts[e];
+            pre[e + 1] = pre[e] + (e < tc.n_exact ? c : 0u);
         });
-        // the lane's flags of this quarter as two 64-bit words: bit 8 e + b = stream (lane, 8 quarter + b) flagged by task e
-        const u32 qsh = 8u * (tid >> 6);
-        u64 f0 = 0, f1 = 0;
-        static_for<0, (int)MAX_EXACT>([&](auto ec) {
-            constexpr u32 e = (u32)decltype(ec)::value;
-            const u64 byte = e < n_exact ? (u64)((hw[e] >> qsh) & 0xFFu) : 0ull;
-            if constexpr (e < 8) f0 |= byte << (8 * e);
-            else f1 |= byte << (8 * (e - 8));
-        });
-        n_flags = (u32)__builtin_popcountll(f0) + (u32)__builtin_popcountll(f1);
-        // per-wave lists, ballot-compacted: wave-uniform loops, no atomics (the trip count is the largest number of flags any
-        // lane of the wave has in its quarter)
-        const u32 wv = tid >> 6;
-        prf_lds_u16 *mylist = flags + wv * FLAG_CAP_WAVE;
-        u32 cnt = 0;  // wave-uniform
-        for (int half = 0; half < 2; half++) {
-            u64 f = half ? f1 : f0;
-            for (;;) {
-                const u64 bal = __builtin_amdgcn_ballot_w64(f != 0);
-                if (bal == 0) break;
-                if (f) {
-                    const u32 x = (u32)__builtin_ctzll(f);
-                    f &= f - 1;
-                    const u32 at = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
-                    if (at < FLAG_CAP_WAVE) mylist[at] = (unsigned short)(rl | (((x & 7u) + qsh) << 6) | (((x >> 3) + 8u * (u32)half) << 11));
-                }
-                cnt += (u32)__builtin_popcountll(bal);
-            }
-        }
-        if (rl == 0) flag_cnt[wv] = cnt;
-        PRF_VSTAMP(12);
-        __syncthreads();
-        PRF_VSTAMP(13);
-        const u32 e0 = flag_cnt[0], e1 = e0 + flag_cnt[1], e2 = e1 + flag_cnt[2], total = e2 + flag_cnt[3];
-        if (flag_cnt[0] <= FLAG_CAP_WAVE && flag_cnt[1] <= FLAG_CAP_WAVE && flag_cnt[2] <= FLAG_CAP_WAVE && flag_cnt[3] <= FLAG_CAP_WAVE) {
-            for (u32 idx = tid; idx < total; idx += (u32)NTH) {
-                const u32 slot_idx = idx < e0 ? idx : (idx < e1 ? FLAG_CAP_WAVE + (idx - e0) : (idx < e2 ? 2 * FLAG_CAP_WAVE + (idx - e1) : 3 * FLAG_CAP_WAVE + (idx - e2)));
-                const u32 f = flags[slot_idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
-                // (a clean tile's first stream looks at positions in front of the tile, where N is possible and the window
-                // has no not-ACGT plane: general routine)
-                if (fast && ((frl | fbit) || wc.x)) win_verify_flag(tc, wc, frl, fbit, k);
-                else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u, true);
-            }
-        } else {  // a tile of long runs: every thread takes its own flags
-            for (int half = 0; half < 2; half++) {
-                u64 f = half ? f1 : f0;
-                while (f) {
-                    const u32 x = (u32)__builtin_ctzll(f);
-                    f &= f - 1;
-                    verify_stream(tc.tile_base + (u64)(((x & 7u) + qsh) * 64u + rl) * T, tc.k_exact0 + (x >> 3) + 8u * (u32)half, 0u, true);
-                }
-            }
+        const u32 total = pre[MAX_EXACT];
+        if (tid == 0) n_flags = total;
+        for (u32 idx = tid; idx < total; idx += (u32)NTH) {
+            u32 e = 0;
+            static_for<1, (int)MAX_EXACT>([&](auto ec) { e += idx >= pre[decltype(ec)::value] ? 1u : 0u; });
+            u32 first = 0;
+            static_for<1, (int)MAX_EXACT>([&](auto ec) {
+                constexpr u32 i = (u32)decltype(ec)::value;
+                first = e >= i ? pre[i] : first;
+            });
+            const u32 f = lists[e * FLAGS_PER_TASK + (idx - first)], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + e;
+            // (a clean tile's first stream looks at positions in front of the tile, where N is possible and the window
+            // has no not-ACGT plane: general routine)
+            if (fast && ((frl | fbit) || wc.x)) win_verify_flag(tc, wc, frl, fbit, k);
+            else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u, true);
         }
     }
     PRF_VSTAMP(14);
@@ -635,6 +598,28 @@ struct Emit {
     int lane;
     u32 cnt;                 // records in it (wave-uniform)
     u32 flushed;             // records verified in early flushes (wave-uniform)
+
+    // Exact tasks: the lanes' words of ONE task -> the task's list of flags (lane | stream bit << 6), ballot-compacted; the
+    // count goes behind the lists.  A task with more flags than its list holds (a tile of long runs) verifies the surplus on
+    // the spot with the general routine (rows straight to the slab, like a flushed record list).
+    __device__ __forceinline__ void push_flags(u32 word, u32 e, u32 k, prf_lds_u32 *hotw, u32 n_exact) {
+        typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
+        prf_lds_u16 *list = (prf_lds_u16 *)hotw + e * FLAGS_PER_TASK;
+        u32 n = 0;  // wave-uniform
+        for (;;) {
+            const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
+            if (bal == 0) break;
+            if (word) {
+                const u32 bit = (u32)__builtin_ctz(word);
+                word &= word - 1;
+                const u32 at = n + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                if (at < FLAGS_PER_TASK) list[at] = (unsigned short)((u32)lane | (bit << 6));
+                else verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u, false);
+            }
+            n += (u32)__builtin_popcountll(bal);
+        }
+        if (lane == 0) hotw[n_exact * 64u + e] = n < FLAGS_PER_TASK ? n : FLAGS_PER_TASK;
+    }
 
     __device__ __forceinline__ void push_word(u32 word, u32 k, u32 sc) {
         const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
@@ -879,8 +864,7 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, 
             if (task.stride == 1) group_task<HASX, NC, true>(vimg, ximg, lane, task.k0, task.valid, 1u, em);
             else group_task<HASX, NC, false>(vimg, ximg, lane, task.k0, task.valid, task.stride, em);
         } else {
-            // the lane's word for this task goes to LDS as it is: no ballot, no list (verify_all)
-            hotw[(u32)task.item0 * 64u + (u32)lane] = exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind);
+            em.push_flags(exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind), task.item0, task.k0, hotw, plan.n_exact);
         }
     }
 }
@@ -1004,7 +988,6 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             const u32 kk = v & 7u;
             if (task.kind == 0 && ((task.valid >> kk) & 1u))
                 bitems[(u32)task.item0 + (u32)__builtin_popcount((u32)task.valid & ((1u << kk) - 1u))] = ((u32)task.k0 + kk) | ((u32)task.stride << 16);
-            if (task.kind != 0 && kk == 0) hotw[g.plan.n_exact * 64u + task.item0] = (u32)task.k0 | ((u32)task.kind << 16);
         }
         {
             prf_lds_u32 *cof_lds = bitems + g.plan.n_group_k;
