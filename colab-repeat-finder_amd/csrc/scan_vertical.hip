@@ -39,6 +39,7 @@
 // leaves the device sorted by (contig, start, end), which is what the reference's sorted() returns (:81).
 // Exactness argument: DESIGN.md.
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -1109,39 +1110,46 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const u32 n_rows = n_sorted + n_direct;  // rows beyond the list's capacity were counted in n_direct
     if (n_sorted) {
         // P = 256 / n threads per row (a power of two, adjacent lanes): each counts the smaller keys of its share of the
-        // list, the shares are added up across the P lanes
+        // list, the shares are added up across the P lanes.  Dependent LDS round trips are what this phase costs (~500 cycles
+        // each with the other workgroups' scans on the CU): the row's own key, end and motif size and the first 32 keys of
+        // the lane's share are ONE batch of reads; the shares are added with DPP moves, not LDS shuffles.
         const u32 lg = n_sorted > 128u ? 0u : (n_sorted > 64u ? 1u : (n_sorted > 32u ? 2u : (n_sorted > 16u ? 3u : 4u)));
         const u32 P = 1u << lg, row = (u32)tid >> lg, part = (u32)tid & (P - 1u);
         prf_lds_u32 *keys = smem_row_keys();
-        const u32 mine = row < n_sorted ? keys[row] : 0u;
+        typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
+        prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)keys;
+        const u32 r = row < n_sorted ? row : 0u;  // (lanes without a row read row 0: harmless)
+        const u32 mine = keys[r];
+        const u64 end = smem_row_ends()[r];
+        const u32 kk = smem_row_ks()[r];
         u32 rank = 0;
-        if (row < n_sorted) {
-            // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, four in flight
-            // (reads past the list stay inside the dead image)
-            typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
-            prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)keys;
-            for (u32 c0 = part; 4u * c0 < n_sorted; c0 += 4u * P) {
-                prf_u32x4 v[4];
+        // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, eight reads in flight
+        // (reads past the list stay inside the dead image)
+        for (u32 c0 = part; 4u * c0 < n_sorted; c0 += 8u * P) {
+            prf_u32x4 v[8];
 #pragma unroll
-                for (u32 j = 0; j < 4u; j++) v[j] = k4[c0 + j * P];
+            for (u32 j = 0; j < 8u; j++) v[j] = k4[c0 + j * P];
 #pragma unroll
-                for (u32 j = 0; j < 4u; j++) {
-                    const u32 b0 = 4u * (c0 + j * P);
-                    rank += (b0 < n_sorted && v[j].x < mine) ? 1u : 0u;
-                    rank += (b0 + 1u < n_sorted && v[j].y < mine) ? 1u : 0u;
-                    rank += (b0 + 2u < n_sorted && v[j].z < mine) ? 1u : 0u;
-                    rank += (b0 + 3u < n_sorted && v[j].w < mine) ? 1u : 0u;
-                }
+            for (u32 j = 0; j < 8u; j++) {
+                const u32 b0 = 4u * (c0 + j * P);
+                rank += (b0 < n_sorted && v[j].x < mine) ? 1u : 0u;
+                rank += (b0 + 1u < n_sorted && v[j].y < mine) ? 1u : 0u;
+                rank += (b0 + 2u < n_sorted && v[j].z < mine) ? 1u : 0u;
+                rank += (b0 + 3u < n_sorted && v[j].w < mine) ? 1u : 0u;
             }
         }
-        for (u32 o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);  // wave-uniform trip count
+        // sum over the P adjacent lanes of a row (wave-uniform P): xor 1, xor 2 by quad permutes; after those all lanes of a
+        // quad agree, so the half-row and row mirrors pair the right partners for 4 and 8
+        if (P >= 2u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0xB1, 0xF, 0xF, true);
+        if (P >= 4u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x4E, 0xF, 0xF, true);
+        if (P >= 8u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x141, 0xF, 0xF, true);
+        if (P >= 16u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x140, 0xF, 0xF, true);
         const u32 dst = n_direct + rank;
         if (row < n_sorted && part == 0 && dst < tc.slab_cap) {
-            const u64 end = smem_row_ends()[row];
             prf_hit_dev h;
             h.start = tc.tile_base + (mine >> 16) - tc.contig_base;
             h.end = end - tc.contig_base;
-            h.k = smem_row_ks()[row];
+            h.k = kk;
             h.contig = tc.contig;
             tc.slab[dst] = h;
         }
@@ -1421,9 +1429,12 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
     if (args.n_launch == 0) return hipSuccess;
     const dim3 grid(args.n_launch), block(NTH);
+    // PRF_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, to measure the scan at a lower occupancy
+    static const u32 lds_pad = getenv("PRF_LDS_PAD") ? (u32)atoi(getenv("PRF_LDS_PAD")) : 0u;
+    const u32 lds = args.plan.lds_bytes + lds_pad;
     switch (args.plan.nc) {
-        case 72: hipLaunchKernelGGL((prf_vscan_kernel<72>), grid, block, args.plan.lds_bytes, s, args); break;
-        case 80: hipLaunchKernelGGL((prf_vscan_kernel<80>), grid, block, args.plan.lds_bytes, s, args); break;
+        case 72: hipLaunchKernelGGL((prf_vscan_kernel<72>), grid, block, lds, s, args); break;
+        case 80: hipLaunchKernelGGL((prf_vscan_kernel<80>), grid, block, lds, s, args); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
