@@ -21,9 +21,10 @@ uniform ACGT, seed 2026, motif 1-100), hg38-random (the hg38 lengths, uniform AC
 
 N > 1 is STRONG scaling on the same workload: one process per GPU, every rank holds the whole genome and scans its share
 of it (multi_gpu.plan_parts: position ranges cut at tile multiples, balanced by tile cost; a row belongs to the share that
-holds its first position, so no halo and no exchange), then the rows are concatenated on rank 0 with one padded RCCL
-gather per step, inside the timed region (a communication thread issues the gathers from a ring of send buffers while the
-main thread scans on; every gather has completed when the timed region ends).
+holds its first position, so no halo and no exchange), then the rows -- packed to 8 bytes each on the device
+(prf_last_hits_packed_to_device) -- are concatenated on rank 0 with one padded RCCL gather per step, inside the timed region
+(a communication thread issues the gathers from a ring of send buffers while the main thread scans on; every gather has
+completed when the timed region ends).
 
 Rank 0 prints ONE JSON line.  `value` is whole-job Gbp/s from the wall clock (max over ranks); the `roofline` object prices
 the dominant kernel (prf_vscan_kernel) with the HIP events recorded around each of its launches in the timed region on the
@@ -206,12 +207,15 @@ def main():
         import threading
         cap = torch.tensor([n_rows_local], device=tdev, dtype=torch.int64)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        gather_cap = int(cap.item()) + 1                                     # 24-byte rows + one count record
+        gather_cap = int(cap.item())
+        SIDE = 1024                                                          # rows longer than 65 534 bp travel whole
+        n_words = gather_cap + 1 + 3 * SIDE                                  # 8-byte wire rows + count word + side list
+        bases = genome.contig_bases()
         # The gather of step i runs on a communication thread while the main thread scans step i+1, i+2, ...:
         # NBUF send buffers cycle between the two (the scan and the collectives release the GIL).
         NBUF = 4
-        send_devs = [torch.zeros((gather_cap, 3), dtype=torch.int64, device="cuda") for _ in range(NBUF)]
-        sends = send_devs if tdev == "cuda" else [torch.zeros((gather_cap, 3), dtype=torch.int64) for _ in range(NBUF)]
+        send_devs = [torch.zeros(n_words, dtype=torch.int64, device="cuda") for _ in range(NBUF)]
+        sends = send_devs if tdev == "cuda" else [torch.zeros(n_words, dtype=torch.int64) for _ in range(NBUF)]
         recvs = [[torch.zeros_like(sends[0]) for _ in range(world)] if rank == 0 else None for _ in range(NBUF)]
         free_q, work_q = queue.Queue(), queue.Queue()
         for b in range(NBUF):
@@ -255,10 +259,12 @@ def main():
     def step():
         if world > 1:
             b = take_buffer()                                                # blocks only if all NBUF gathers are pending
-            ctx.set_row_sink(send_devs[b].data_ptr(), gather_cap - 1)       # the gather kernel compacts the rows straight into
-            _, st = scan(False)                                             # the send buffer and writes the count record
+            _, st = scan(False)                                              # rows sorted and compact on the device ...
             step_no[0] += 1
-            work_q.put((b, step_no[0] % args.gather_every == 0))
+            do_gather = step_no[0] % args.gather_every == 0
+            if do_gather:                                                    # ... packed into the send buffer: 8 bytes a row
+                ctx.last_hits_packed_to_device(genome, send_devs[b].data_ptr(), gather_cap, SIDE)
+            work_q.put((b, do_gather))
         else:
             _, st = scan(False)
         return st
@@ -336,10 +342,9 @@ def main():
         # the last gather must hold every rank's rows; the shares are in genome order, so their concatenation IS the
         # whole scan's sorted row array
         recv = recvs[comm_state["last"]]
-        counts = [int(r[gather_cap - 1, 0].item()) for r in recv]
-        parts = [np.ascontiguousarray(r[:c].cpu().numpy()).view(rows.dtype).reshape(-1) for r, c in zip(recv, counts)]
+        parts = [multi_gpu.unpack_rows(r.cpu().numpy(), gather_cap, SIDE, bases, prf_native.tile_positions()) for r in recv]
         got = np.concatenate(parts)
-        gathered_ok = bool(sum(counts) == n_rows_total and np.array_equal(got, rows_whole))
+        gathered_ok = bool(len(got) == n_rows_total and np.array_equal(got, rows_whole))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bp / (elapsed / args.steps) / 1e9
@@ -363,11 +368,11 @@ def main():
                        "steps_in_flight": 2 if pipelined else 1,
                        "multi_gpu": ({"sharding": "every rank holds the genome and scans its share of the tiles (prf_genome_select); "
                                                   "no data-path collective",
-                                      "gather": f"one padded RCCL gather of 24-byte rows to rank 0 every {args.gather_every} step(s), "
-                                                "overlapped with the following scans",
+                                      "gather": f"one padded RCCL gather of 8-byte wire rows (prf_last_hits_packed_to_device) to rank 0 every "
+                                                f"{args.gather_every} step(s), overlapped with the following scans",
                                       "gather_verified": gathered_ok,
                                       "gather_ms_mean": round(float(np.mean(comm_state["gather_s"])) * 1e3, 4) if comm_state["gather_s"] else None,
-                                      "gather_rows_per_rank_max": gather_cap - 1,
+                                      "gather_rows_per_rank_max": gather_cap, "gather_bytes_per_rank": 8 * n_words,
                                       "scan_kernel_ms_per_rank": [round(x, 5) for x in kernel_ms_ranks]} if world > 1 else "n/a")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5),
@@ -386,8 +391,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sample_fn(n), args.kmin, args.kmax, args.min_repeats, args.min_span,
                                                (sample_what % n) + " of the workload")
         print(json.dumps(out), flush=True)
-    if world > 1:
-        ctx.set_row_sink(None, 0)
     genome.free()
     ctx.close()
     if world > 1:

@@ -1021,6 +1021,38 @@ int prf_genome_select(prf_genome *g, const prf_part *parts, int n_parts) {
     }
 }
 
+int prf_last_hits_packed_to_device(prf_ctx *c, const prf_genome *g, void *dst, uint64_t capacity_rows, uint64_t side_capacity,
+                                   uint64_t *n_rows) {
+    if (!c || !g || g->ctx != c || !n_rows || !dst) return fail(PRF_EINVAL, "prf_last_hits_packed_to_device: bad arguments");
+    HIPCHK(hipSetDevice(c->dev));
+    *n_rows = c->last_nhits;
+    if (c->last_nhits > capacity_rows)
+        return fail(PRF_EINVAL, "the packed row buffer holds %llu rows, the scan found %llu", (unsigned long long)capacity_rows,
+                    (unsigned long long)c->last_nhits);
+    u64 *words = (u64 *)dst;
+    u64 *side_cnt = c->d_counters + PRF_CNT_CAND;  // (a spare device word: the generic path's counters are idle here)
+    HIPCHK(hipMemsetAsync(side_cnt, 0, sizeof(u64), c->stream));
+    HIPCHK(prf_launch_pack_rows(c->stream, c->last_rows, c->last_nhits, g->d_base, words, capacity_rows, side_capacity, side_cnt));
+    u64 *stage = c->h_counters + PRF_CNT_N + 2;  // spare pinned words behind the counter block
+    HIPCHK(hipMemcpyAsync(stage, side_cnt, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const u64 n_side = stage[0];
+    if (n_side > side_capacity)
+        return fail(PRF_EINVAL, "the side list holds %llu rows, %llu rows are longer than 65534", (unsigned long long)side_capacity,
+                    (unsigned long long)n_side);
+    stage[1] = c->last_nhits | (n_side << 40);
+    HIPCHK(hipMemcpyAsync(words + capacity_rows, stage + 1, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PRF_OK;
+}
+
+int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capacity, uint64_t *n_contigs) {
+    if (!g || !n_contigs || (capacity && !bases)) return fail(PRF_EINVAL, "prf_genome_contig_bases: bad arguments");
+    *n_contigs = g->base.size();
+    for (size_t i = 0; i < g->base.size() && i < capacity; i++) bases[i] = g->base[i];
+    return PRF_OK;
+}
+
 int prf_plan_describe(uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span, char *buf, uint64_t buf_len) {
     if (!buf || buf_len == 0) return fail(PRF_EINVAL, "prf_plan_describe: no buffer");
     std::string out;

@@ -61,3 +61,32 @@ hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sin
     hipLaunchKernelGGL(prf_hbm_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const uint4 *)p, bytes / 16, sink);
     return hipGetLastError();
 }
+
+// ---- rows (24 bytes) -> 8-byte wire words for the multi-GPU gather (include/prf.h, prf_last_hits_packed_to_device):
+// [63:41] tile (global position / 65536), [40:25] start in the tile, [24:9] span (end - start, clipped to 65535), [8:0] motif size.
+// A row whose span does not fit 16 bits also goes, whole, to the side list behind the count word.
+__global__ __launch_bounds__(256) void prf_pack_rows_kernel(const prf_hit_dev *__restrict__ rows, u64 n, const u64 *__restrict__ contig_base,
+                                                            u64 *__restrict__ dst, u64 cap, u64 side_cap, u64 *__restrict__ side_cnt) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i >= cap) return;
+    const prf_hit_dev h = rows[i];
+    const u64 gpos = contig_base[h.contig] + h.start, span = h.end - h.start;
+    const u64 s16 = span < 65535ull ? span : 65535ull;
+    dst[i] = ((gpos >> 16) << 41) | ((gpos & 0xFFFFull) << 25) | (s16 << 9) | (u64)(h.k & 511u);
+    if (span >= 65535ull) {
+        const u64 j = atomicAdd(side_cnt, 1ull);
+        if (j < side_cap) {
+            u64 *o = dst + cap + 1 + 3 * j;
+            o[0] = h.start;
+            o[1] = h.end;
+            o[2] = (u64)h.k | ((u64)h.contig << 32);
+        }
+    }
+}
+
+hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, const u64 *contig_base, u64 *dst, u64 cap, u64 side_cap,
+                                u64 *side_cnt) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(prf_pack_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, rows, n, contig_base, dst, cap, side_cap, side_cnt);
+    return hipGetLastError();
+}

@@ -69,6 +69,30 @@ def plan_parts(lengths, world, tile, classes=None):
     return shares
 
 
+def unpack_rows(words, capacity, side_capacity, bases, tile):
+    """Decode the 8-byte wire format of prf_last_hits_packed_to_device (include/prf.h): `words` = capacity packed rows, one
+    count word, 3 * side_capacity words of long rows.  bases: Genome.contig_bases().  Returns a ROW_DTYPE array."""
+    words = np.asarray(words).view(np.uint64).reshape(-1)
+    count = int(words[capacity])
+    n, n_side = count & ((1 << 40) - 1), count >> 40
+    w = words[:n]
+    gpos = (w >> np.uint64(41)) * np.uint64(tile) + ((w >> np.uint64(25)) & np.uint64(0xFFFF))
+    span = (w >> np.uint64(9)) & np.uint64(0xFFFF)
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    bases = np.asarray(bases, dtype=np.uint64)
+    contig = np.searchsorted(bases, gpos, side="right") - 1
+    rows["contig"] = contig
+    rows["start"] = gpos - bases[contig]
+    rows["end"] = rows["start"] + span
+    rows["k"] = (w & np.uint64(511)).astype(np.uint32)
+    if n_side:
+        side = words[capacity + 1:capacity + 1 + 3 * n_side].reshape(n_side, 3)
+        full = {(int(c), int(s), int(k)): int(e) for s, e, kc in side.tolist() for k, c in [(kc & 0xFFFFFFFF, kc >> 32)]}
+        for i in np.nonzero(span == np.uint64(0xFFFF))[0].tolist():
+            rows["end"][i] = full[(int(rows["contig"][i]), int(rows["start"][i]), int(rows["k"][i]))]
+    return rows
+
+
 def rows_to_tensor(rows, capacity, torch, device):
     """(capacity+1, 3) int64 tensor: 24-byte rows as three int64 words, the row count in the last row."""
     t = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)

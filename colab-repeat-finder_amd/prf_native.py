@@ -63,7 +63,8 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_genome_free", "prf_genome_positions", "prf_scan_genome", "prf_scan", "prf_free_hits",
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
-           "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split"]
+           "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split", "prf_last_hits_packed_to_device",
+           "prf_genome_contig_bases"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -107,6 +108,8 @@ def load_library():
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.prf_last_hits_to_device.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_set_row_sink.argtypes = [vp, vp, ctypes.c_uint64]
+        lib.prf_last_hits_packed_to_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_genome_contig_bases.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_genome_async.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_wait.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(ScanStats)]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
@@ -208,6 +211,15 @@ class Genome:
                                                                   ctypes.byref(n)))
         return out[:n.value]
 
+    def contig_bases(self):
+        """First position of every contig in the genome's coordinate space (numpy uint64)."""
+        import numpy as np
+        n = ctypes.c_uint64(0)
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_contig_bases(self._h, None, 0, ctypes.byref(n)))
+        out = (ctypes.c_uint64 * max(1, n.value))()
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_contig_bases(self._h, out, n.value, ctypes.byref(n)))
+        return np.array(out[:n.value], dtype=np.uint64)
+
     def scan_async(self, kmin, kmax, min_repeats, min_span):
         """Enqueue a scan (at most two in flight); returns its serial number for Context.scan_wait()."""
         seq = ctypes.c_uint64(0)
@@ -278,6 +290,14 @@ class Context:
         n = ctypes.c_uint64(0)
         _check(self.lib, self.lib.prf_last_hits_to_device(self._h, ctypes.c_void_p(dst_ptr), capacity_rows,
                                                           1 if count_row else 0, ctypes.byref(n)))
+        return n.value
+
+    def last_hits_packed_to_device(self, genome, dst_ptr, capacity_rows, side_capacity):
+        """The last scan's rows as 8-byte wire words (+ count word + side list of long rows) in caller-owned device memory of
+        capacity_rows + 1 + 3 * side_capacity words; returns the row count.  multi_gpu.unpack_rows() decodes."""
+        n = ctypes.c_uint64(0)
+        _check(self.lib, self.lib.prf_last_hits_packed_to_device(self._h, genome._h, ctypes.c_void_p(dst_ptr), capacity_rows,
+                                                                 side_capacity, ctypes.byref(n)))
         return n.value
 
     def scan_wait(self, seq):

@@ -182,6 +182,17 @@ void prf_free_hits(prf_hits *hits);
  * The copy is complete when the call returns. */
 int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_rows, int count_row, uint64_t *n_rows);
 
+/* The same hand-off in the 8-byte wire format of the multi-GPU gather (a third of the bytes on the xGMI links): word i =
+ * tile << 41 | start in the tile << 25 | min(end - start, 65535) << 9 | k, where tile * prf_tile_positions() + start in the
+ * tile is the row's first position in the genome's coordinate space (contig c begins at prf_genome_contig_bases()[c]).
+ * dst_device holds capacity_rows words, then ONE count word (rows | long rows << 40), then side_capacity full rows of three
+ * words (start, end, k | contig << 32) for the rows whose span does not fit 16 bits.  multi_gpu.unpack_rows() decodes.
+ * Fails with PRF_EINVAL if the scan found more rows than capacity_rows (or more long rows than side_capacity). */
+int prf_last_hits_packed_to_device(prf_ctx *ctx, const prf_genome *g, void *dst_device, uint64_t capacity_rows,
+                                   uint64_t side_capacity, uint64_t *n_rows);
+/* First position of every contig in the genome's coordinate space (multiples of prf_tile_positions()). */
+int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capacity, uint64_t *n_contigs);
+
 /* ---- the data formats either side of the path (host code, no GPU) ------------------------------------------
  * FASTA reader: what the reference takes from pyfastx.Fasta (perfect_repeat_finder.py:117,130,136-143): entries in
  * file order, name = header up to the first white space, sequence = the record's lines joined (case kept).

@@ -512,6 +512,40 @@ def test_config_c4_hg38_sized_genome_on_one_gpu(ctx):
         g.free()
 
 
+def test_config_c3_chr1_sized_stand_in_generated_on_the_device(ctx):
+    """BASELINE config C3's workload as bench.py --workload chr1 times it: a chr1-sized contig (248 956 422 bp) of the stand-in
+    recipe (N blocks at both ends, a 10 Mbp centromere-like gap, one planted repeat per 588 positions), generated on the
+    device.  Too long for the oracle as a whole: row-set properties, fused == generic row for row, and the oracle on windows
+    of the host recipe at every N-block edge (where tiles with N in reach, their late-staged windows and the tile
+    ownership rule act) and in the middle."""
+    import prf_native
+    import synth
+    from oracle import prf_oracle
+    n, seed = synth.CHR1_LEN, 1
+    g = ctx.standin([n], [seed], 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.positions == n and st.sorted_on_device == 1
+        starts, ends, ks = rows["start"].astype(np.int64), rows["end"].astype(np.int64), rows["k"].astype(np.int64)
+        assert 400_000 < len(rows) < 520_000
+        assert np.all((starts[1:] > starts[:-1]) | ((starts[1:] == starts[:-1]) & (ends[1:] > ends[:-1])))
+        assert np.all(ends - starts >= np.maximum(3 * ks, 9))
+        n_head, n_tail, gap_lo, gap_hi = synth.standin2_layout(n)
+        assert starts.min() >= n_head and ends.max() <= n - n_tail and not np.any((starts < gap_hi) & (ends > gap_lo))
+        rows2, st2 = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert st2.path == 0 and np.array_equal(rows, rows2)
+        win, margin = 600_000, 1_000
+        for off in (0, gap_lo - win // 2, gap_hi - win // 2, n // 2, n - win):
+            chunk = synth.standin2(n, seed, off, win).tobytes()
+            want = [(s + off, e + off, k) for s, e, _m, k in prf_oracle.detect_rows(chunk, 1, 50, 3, 9)
+                    if s >= margin and e <= win - margin]
+            sel = (starts >= off + margin) & (ends <= off + win - margin)
+            got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
+            assert got == want and len(want) > 400, off
+    finally:
+        g.free()
+
+
 def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
     """PRF_SCAN_DEFER_TIMING + prf_scan_timings (what bench.py's timed loop uses) and the device-to-device
     hand-off of rows with the trailing count record (what its multi-GPU gather ships)."""
@@ -618,6 +652,27 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
         assert ctx.last_hits_to_device(buf.data_ptr(), len(rows)) == len(rows)
         raw = np.ascontiguousarray(buf.cpu().numpy()[:len(rows)]).view(rows.dtype).reshape(-1)
         assert np.array_equal(raw, rows)
+        # the 8-byte wire format of the multi-GPU gather: packed on the device, decoded on the host
+        import multi_gpu
+        import prf_native
+        cap, side = len(rows) + 5, 4
+        words = torch.zeros(cap + 1 + 3 * side, dtype=torch.int64, device="cuda")
+        assert ctx.last_hits_packed_to_device(g, words.data_ptr(), cap, side) == len(rows)
+        got = multi_gpu.unpack_rows(words.cpu().numpy(), cap, side, g.contig_bases(), prf_native.tile_positions())
+        assert np.array_equal(got, rows)
+        with pytest.raises(prf_native.PrfError):
+            ctx.last_hits_packed_to_device(g, words.data_ptr(), len(rows) - 1, side)       # too small: refused
+    finally:
+        g.free()
+    long_run = [b"ACGT" * 10 + b"A" * 70_000 + b"C", b"GT" * 40_000 + b"ACGTTGCA"]         # spans that do not fit 16 bits
+    g = ctx.load(long_run, 50)
+    try:
+        rows, _ = g.scan(1, 50, 3, 9)
+        assert rows_as_tuples(rows) == [(c, a, b, k) for c, s_ in enumerate(long_run) for a, b, k in oracle_rows(s_, 1, 50, 3, 9)]
+        assert (0, 40, 70_040, 1) in rows_as_tuples(rows) and (1, 0, 80_000, 2) in rows_as_tuples(rows)
+        words = torch.zeros(2 + 1 + 3 * 4, dtype=torch.int64, device="cuda")
+        ctx.last_hits_packed_to_device(g, words.data_ptr(), 2, 4)
+        assert np.array_equal(multi_gpu.unpack_rows(words.cpu().numpy(), 2, 4, g.contig_bases(), prf_native.tile_positions()), rows)
     finally:
         g.free()
     dense = (b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG") * 2500
