@@ -511,9 +511,10 @@ __device__ __noinline__ void flush_records(prf_lds_cu64 *recs, int wave, u32 n, 
 }
 
 // Candidates -> rows, all waves together at the end of the tile.
-//  * exact tasks left one word per (task, lane) in LDS: thread (lane, quarter) takes the streams of its lane whose bit lies
-//    in its quarter of the word and that any task flagged, one stream at a time, all flagging motif sizes at once;
-//  * group-task records and the boundary items are taken by the lanes from the last thread down.
+//  * exact tasks left ballot-compacted lists of (stream, task) flags in LDS: one index space, dealt to the threads from
+//    thread 0 up;
+//  * group-task records are taken by the upper two waves, alternately; the boundary items by the lower half, from its last
+//    thread down.
 // Returns the number of (stream, exact task) flags this thread looked at (statistics).
 __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bitems, u32 n_bitems, u32 tid, u64 *dbg) {
 #ifdef PRF_STAMPS
@@ -565,26 +566,30 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
         }
     }
     PRF_VSTAMP(14);
-    {
+    // ---- group-task records: the upper half of the workgroup, alternating between its two waves (a wave's pass costs the
+    // same with 1 or 64 records; the flags keep the lower waves busy meanwhile)
+    if (tid >= (u32)NTH / 2u) {
         prf_lds_u32 *cg = smem_rec_cnt();
         const u32 c0 = cg[0], c1 = c0 + cg[1], c2 = c1 + cg[2], n = c2 + cg[3];
-        for (u32 idx = (u32)NTH - 1u - tid; idx < n + n_bitems; idx += (u32)NTH) {
-            if (idx < n) {
-                const u32 slot_idx = idx < c0 ? idx : (idx < c1 ? REC_PER_WAVE + (idx - c0) : (idx < c2 ? 2 * REC_PER_WAVE + (idx - c1) : 3 * REC_PER_WAVE + (idx - c2)));
-                const u64 rec = recs[slot_idx];
-                const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
-                u32 word = (u32)(rec >> 17);
-                while (word) {
-                    const u32 bit = (u32)__builtin_ctz(word);
-                    word &= word - 1;
-                    const u32 sq = (bit * 64u + rl) * T;
-                    if (fast && (sq >= 32u || wc.x)) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
-                    else verify_stream(tc.tile_base + sq, k, sc, true);
-                }
-            } else {  // boundary item
-                const u32 it = bitems[idx - n];
-                boundary_item(tc, wc, fast, it & 0xFFFFu, it >> 16);
+        const u32 up = (u32)NTH - 1u - tid;  // 0 .. 127: thread 255, 254, ...
+        for (u32 idx = 2u * (up & 63u) + (up >> 6); idx < n; idx += (u32)NTH / 2u) {
+            const u32 slot_idx = idx < c0 ? idx : (idx < c1 ? REC_PER_WAVE + (idx - c0) : (idx < c2 ? 2 * REC_PER_WAVE + (idx - c1) : 3 * REC_PER_WAVE + (idx - c2)));
+            const u64 rec = recs[slot_idx];
+            const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
+            u32 word = (u32)(rec >> 17);
+            while (word) {
+                const u32 bit = (u32)__builtin_ctz(word);
+                word &= word - 1;
+                const u32 sq = (bit * 64u + rl) * T;
+                if (fast && (sq >= 32u || wc.x)) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
+                else verify_stream(tc.tile_base + sq, k, sc, true);
             }
+        }
+    } else {
+        // ---- boundary items: the lower half, from its last thread down (the flags fill it from the first thread up)
+        for (u32 idx = (u32)NTH / 2u - 1u - tid; idx < n_bitems; idx += (u32)NTH / 2u) {
+            const u32 it = bitems[idx];
+            boundary_item(tc, wc, fast, it & 0xFFFFu, it >> 16);
         }
     }
     return n_flags;
@@ -832,30 +837,42 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, prf_lds
     return hot;
 }
 
-template <int K, int NC>
-__device__ __forceinline__ u32 exact_any_m(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx, u32 M) {
-    u32 hot = 0;
-    static_for<K, SMALL_M>([&](auto mc) {  // M(k) >= k because min_repeats >= 2
-        constexpr int MM = decltype(mc)::value;
-        if (M == (u32)MM) hot = exact_stream<K, MM, NC>(vimg, ximg, lane, hasx);  // wave-uniform
-    });
-    return hot;
+// The (K, M) variants, K <= M < SMALL_M, numbered densely in (K, M) order; the dispatch is a binary search over that number
+// (7 wave-uniform branches; a chain of `if (k == K)` tests cost a task about thirty taken branches).
+constexpr int exact_variants() { return (SMALL_M - 1) * SMALL_M / 2; }
+constexpr int exact_variant_of(int K, int M) { return (K - 1) * (2 * SMALL_M - K) / 2 + (M - K); }
+constexpr int exact_variant_k(int v) {
+    int K = 1;
+    while (exact_variant_of(K + 1, K + 1) <= v) K++;
+    return K;
+}
+template <int LO, int HI, int NC>
+__device__ __forceinline__ u32 exact_dispatch(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx, u32 v) {
+    if constexpr (LO == HI) {
+        constexpr int K = exact_variant_k(LO), M = K + (LO - exact_variant_of(K, K));
+        static_assert(M >= K && M < SMALL_M && exact_variant_of(K, M) == LO, "variant numbering");
+        return exact_stream<K, M, NC>(vimg, ximg, lane, hasx);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (v <= (u32)MID) return exact_dispatch<LO, MID, NC>(vimg, ximg, lane, hasx, v);  // wave-uniform
+        return exact_dispatch<MID + 1, HI, NC>(vimg, ximg, lane, hasx, v);
+    }
 }
 
 template <int NC>
 __device__ __forceinline__ u32 exact_any(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx, u32 k, u32 M) {
-    u32 hot = 0;
-    static_for<1, SMALL_M>([&](auto kc) {  // (min_repeats - 1) * k <= M < 15
-        constexpr int KK = decltype(kc)::value;
-        if (k == (u32)KK) hot = exact_any_m<KK, NC>(vimg, ximg, lane, hasx, M);  // wave-uniform
-    });
-    return hot;
+    // (min_repeats - 1) * k <= M < SMALL_M and min_repeats >= 2: k <= M
+    const u32 v = (k - 1u) * (2u * (u32)SMALL_M - k) / 2u + (M - k);
+    return exact_dispatch<0, exact_variants() - 1, NC>(vimg, ximg, lane, hasx, v);
 }
 
 template <bool HASX, int NC>
 __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, prf_lds_u32 *hotw, const prf_vplan &plan, int wave, int lane,
                                           Emit &em, u64 *dbg) {
     const u32 t_end = plan.wave_begin[wave + 1];
+#ifdef PRF_STAMPS
+    u64 t_call = 0;
+#endif
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
         const prf_vtask task = plan.tasks[ti];
 #ifdef PRF_STAMPS
@@ -865,9 +882,20 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, 
             if (task.stride == 1) group_task<HASX, NC, true>(vimg, ximg, lane, task.k0, task.valid, 1u, em);
             else group_task<HASX, NC, false>(vimg, ximg, lane, task.k0, task.valid, task.stride, em);
         } else {
+#ifdef PRF_STAMPS
+            const u64 tc0 = __builtin_amdgcn_s_memtime();
+            const u32 word = exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind);
+            asm volatile("" ::"v"(word));
+            t_call += __builtin_amdgcn_s_memtime() - tc0;
+            em.push_flags(word, task.item0, task.k0, hotw, plan.n_exact);
+#else
             em.push_flags(exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind), task.item0, task.k0, hotw, plan.n_exact);
+#endif
         }
     }
+#ifdef PRF_STAMPS
+    if (dbg && lane == 0) dbg[15] = t_call;
+#endif
 }
 
 // Grid: one workgroup per entry of the launch list (tiles in position order).
@@ -896,6 +924,9 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr int extra = NC - 64;
 
     PRF_STAMP(0);
+#ifdef PRF_STAMPS
+    if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+#endif
     // ---- 1. stage ----
     // All global loads of a thread are issued back to back before the first LDS store, so the workgroup pays
     // one memory round trip (a load -> store loop pays one per iteration: measured 7 k cycles per tile).
@@ -1165,6 +1196,9 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         if (n_direct) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
     }
     PRF_STAMP(7);
+#ifdef PRF_STAMPS
+    if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

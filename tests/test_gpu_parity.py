@@ -670,9 +670,9 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
         rows, _ = g.scan(1, 50, 3, 9)
         assert rows_as_tuples(rows) == [(c, a, b, k) for c, s_ in enumerate(long_run) for a, b, k in oracle_rows(s_, 1, 50, 3, 9)]
         assert (0, 40, 70_040, 1) in rows_as_tuples(rows) and (1, 0, 80_000, 2) in rows_as_tuples(rows)
-        words = torch.zeros(2 + 1 + 3 * 4, dtype=torch.int64, device="cuda")
-        ctx.last_hits_packed_to_device(g, words.data_ptr(), 2, 4)
-        assert np.array_equal(multi_gpu.unpack_rows(words.cpu().numpy(), 2, 4, g.contig_bases(), prf_native.tile_positions()), rows)
+        words = torch.zeros(len(rows) + 1 + 3 * 4, dtype=torch.int64, device="cuda")
+        ctx.last_hits_packed_to_device(g, words.data_ptr(), len(rows), 4)
+        assert np.array_equal(multi_gpu.unpack_rows(words.cpu().numpy(), len(rows), 4, g.contig_bases(), prf_native.tile_positions()), rows)
     finally:
         g.free()
     dense = (b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG") * 2500

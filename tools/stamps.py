@@ -5,13 +5,17 @@ import numpy as np
 sys.path.insert(0, 'colab-repeat-finder_amd'); sys.path.insert(0, '.')
 import prf_native, synth
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 50_818_468
-seq = synth.chr_standin(length=L, seed=22, n_head=10_510_000 if L > 2e7 else L // 10, n_tail=10_000).tobytes()
 ctx = prf_native.Context(0)
-g = ctx.load([seq], 50)
+if len(sys.argv) > 2 and sys.argv[2] == 'standin2':   # the default bench workload's recipe, generated on the device
+    g = ctx.standin([L], [1], 50)
+else:
+    seq = synth.chr_standin(length=L, seed=22, n_head=10_510_000 if L > 2e7 else L // 10, n_tail=10_000).tobytes()
+    g = ctx.load([seq], 50)
 for _ in range(3):
     g.scan(1, 50, 3, 9, fetch=False)
 _, st = g.scan(1, 50, 3, 9, fetch=False)
 print('kernel ms', st.phase1_ms)
+st_ms_global = st.phase1_ms
 d = np.fromfile(os.environ['PRF_STAMPS_OUT'], dtype=np.uint64).reshape(-1, 4, 16).astype(np.int64)
 t0 = d[:, :, 0].min()
 names = ['stage', 'bar1', 'scan', 'bar2', 'verify', 'bar3', 'rows']
@@ -40,5 +44,17 @@ for w in range(4):
     print('wave', w, 'task cycles', out)
 
 for w in range(4):
-    print('wave', w, 'verify split: collect flags=%d barrier=%d flags body=%d group+boundary=%d' % tuple(int(np.median(x)) for x in (
-        d[:, w, 12] - d[:, w, 4], d[:, w, 13] - d[:, w, 12], d[:, w, 14] - d[:, w, 13], d[:, w, 5] - d[:, w, 14])))
+    print('wave', w, 'verify: flags part %d, records / boundary part %d' % (int(np.median(d[:, w, 14] - d[:, w, 4])), int(np.median(d[:, w, 5] - d[:, w, 14]))))
+for w in range(4):
+    print('wave', w, 'cycles inside the exact-task functions (sum over the wave\'s exact tasks): median', int(np.median(d[:, w, 15])))
+
+# slot utilisation from the chip-wide 100 MHz counter (slots 12 / 13 = workgroup start / end)
+rs = d[:, :, 12].min(axis=1); re = d[:, :, 13].max(axis=1)
+span = re.max() - rs.min()
+print('kernel span on the 100 MHz counter: %.1f us; workgroup time: p50 %.2f us; slot utilisation (256 CUs x 4): %.3f' % (
+    span / 100.0, np.median(re - rs) / 100.0, (re - rs).sum() / (span * 1024.0)))
+print('core cycles per 10 ns tick (p50 over workgroups): %.2f' % np.median((d[:, 0, 7] - d[:, 0, 0]) / np.maximum(1, d[:, 0, 13] - d[:, 0, 12])))
+# how many workgroups are resident over time (per 5 us bucket)
+edges = np.arange(rs.min(), re.max() + 500, 500)
+res = [(int(((rs < e + 500) & (re > e)).sum())) for e in edges[:-1]]
+print('resident workgroups per 5 us bucket:', res[:8], '...', res[len(res)//2 - 2: len(res)//2 + 2], '...', res[-6:])
