@@ -97,7 +97,7 @@ typedef __attribute__((address_space(3))) const u32 prf_lds_cu32;
 #ifdef PRF_STAMPS
 #define PRF_STAMP(i)                                                                                               \
     do {                                                                                                           \
-        if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define PRF_STAMP(i) do { } while (0)
@@ -898,8 +898,140 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, 
 #endif
 }
 
-// Grid: one workgroup per entry of the launch list (tiles in position order).
+// Grid: persistent workgroups, 4 per CU (or one per entry of the launch list if that is fewer): workgroup b takes the launch
+// slots b, b + gridDim, ...  (tiles in position order; slabs and counts are indexed by slot, so the order of execution does
+// not show in the output).  The global loads of the NEXT tile's staging data are issued at the start of the rows phase of
+// the current one and land in registers while the rows are sorted: the memory round trip in front of every tile (5-8 k
+// cycles of a 45 k-cycle tile, every wave waiting) is off the critical path, and the per-workgroup set-up (boundary items,
+// cofactor table, the constant part of the tile context) is paid once per workgroup instead of once per tile.
 // __launch_bounds__(256, 4): 128 VGPRs; with NC = 72 the 39.6 KB of LDS allow 4 workgroups per CU.
+template <int NC>
+struct StageRegs {
+    static constexpr int extra = NC - 64;
+    static constexpr int NLF = (2 * LW) / NTH;        // full rounds of linear words
+    static constexpr int NLT = (2 * LW) - NLF * NTH;  // tail
+    // virtual-lane slots: (plane, row group, first lanes again).  3 planes x 8 row groups x 16 extra lanes (NC = 80,
+    // tile with N in reach) are 384 slots: two rounds of the 256 threads cover every instantiated width.
+    static constexpr int NXR = (3 * RG * extra + NTH - 1) / NTH;
+    static_assert(3 * RG * extra <= NXR * NTH, "virtual-lane staging rounds do not cover the image width");
+    static_assert(NLF >= 4, "the not-ACGT plane of a tile with N in reach travels in the window's registers");
+    static_assert(NLF % 2 == 0, "linear words travel as pairs");
+    prf_u32x4 vh0, vh1, vl0, vl1;
+    // clean tile: the linear window, two 64-bit words per vector; tile with N in reach: q[0], q[1] = its two X-plane slots.
+    // (One set of registers for both, written by loads only -- no conversion, which would wait for the data -- and the
+    // two kinds of tile are separate branches from the first load to the last: a shared prefix made the compiler wait for
+    // the image loads before it issued the window loads.)
+    prf_u32x4 q[NLF / 2];
+    u64 lt;
+    prf_u32x4 ev[NXR], en[NXR];
+    uint4 info;
+    u32 entry;    // the launch-list entry these registers belong to
+
+    // All global loads of a thread are issued back to back, nothing waits for them here.  Every address is a wave-uniform
+    // base (scalar registers) plus a 32-bit per-thread offset: per-thread 64-bit pointers would be hoisted out of the tile
+    // loop and spilled.
+    __device__ __forceinline__ static prf_u32x4 ld16(const void *ubase, u32 byte_off) {
+        return *reinterpret_cast<const prf_u32x4 *>(reinterpret_cast<const char *>(ubase) + byte_off);
+    }
+    __device__ __forceinline__ static u64 ld8(const void *ubase, u32 byte_off) {
+        return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ubase) + byte_off);
+    }
+    __device__ __forceinline__ void load(const prf_vscan_args &g, u32 e, int tid) {
+        e = (u32)__builtin_amdgcn_readfirstlane((int)e);
+        entry = e;
+        const bool hasx = (e & PRF_LAUNCH_MIXED) != 0;
+        const u64 tile = e & ~PRF_LAUNCH_MIXED;
+        const prf_u32x4 *ph = reinterpret_cast<const prf_u32x4 *>(g.VH) + tile * (RG * 64), *pL = reinterpret_cast<const prf_u32x4 *>(g.VL) + tile * (RG * 64),
+                        *px = reinterpret_cast<const prf_u32x4 *>(g.VX) + tile * (RG * 64);
+        const int np = hasx ? 3 : 2;
+        // slot (rg + 4*j, l) of a plane, rg = tid >> 6, l = tid & 63: slot index tid + 256 j
+        u32 ut = (u32)tid;
+        asm volatile("" : "+v"(ut));  // (opaque: keeps the address arithmetic inside the loop, see above)
+        const u32 o16 = ut * 16u, o8 = ut * 8u;
+        lt = 0;
+        if (hasx) {
+            vh0 = ld16(ph, o16); vh1 = ld16(ph, o16 + 4u * 64u * 16u); vl0 = ld16(pL, o16); vl1 = ld16(pL, o16 + 4u * 64u * 16u);
+            q[0] = ld16(px, o16);
+            q[1] = ld16(px, o16 + 4u * 64u * 16u);
+            static_for<2, NLF / 2>([&](auto ic) { q[decltype(ic)::value] = prf_u32x4{0, 0, 0, 0}; });
+        } else {
+            vh0 = ld16(ph, o16); vh1 = ld16(ph, o16 + 4u * 64u * 16u); vl0 = ld16(pL, o16); vl1 = ld16(pL, o16 + 4u * 64u * 16u);
+            // the planes have readable padding in front
+            const u64 *wh = g.H + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE), *wl = g.L + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE - LW);
+            static_for<0, NLF>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const u32 idx = ut + (u32)(i * NTH);  // one round straddles H -> L
+                const u32 ob = o8 + (u32)(i * NTH * 8);
+                u64 w;
+                if constexpr ((i + 1) * NTH <= LW) w = ld8(wh, ob);
+                else if constexpr (i * NTH >= LW) w = ld8(wl, ob);
+                else w = idx < (u32)LW ? ld8(wh, ob) : ld8(wl, ob);
+                if constexpr (i % 2 == 0) { q[i / 2].x = (u32)w; q[i / 2].y = (u32)(w >> 32); }
+                else { q[i / 2].z = (u32)w; q[i / 2].w = (u32)(w >> 32); }
+            });
+            if (tid < NLT) lt = ld8(wl, o8 + (u32)(NLF * NTH * 8));
+        }
+        const int n_extra = np * RG * extra;
+        static_for<0, NXR>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int sx = (int)ut + r * NTH;
+            ev[r] = prf_u32x4{0, 0, 0, 0};
+            en[r] = ev[r];
+            if (sx < n_extra) {
+                const int p = sx / (RG * extra), erg = (sx / extra) % RG, el = sx % extra;
+                const u32 i0 = (u32)(erg * 64 + el) * 16u, i1 = i0 + (u32)(RG * 64) * 16u;  // the same slot of the next tile
+                if (p == 0) {  // (three branches, not a pointer picked from a table: that table would live in scratch memory)
+                    ev[r] = ld16(ph, i0);
+                    en[r] = ld16(ph, i1);
+                } else if (p == 1) {
+                    ev[r] = ld16(pL, i0);
+                    en[r] = ld16(pL, i1);
+                } else {
+                    ev[r] = ld16(px, i0);
+                    en[r] = ld16(px, i1);
+                }
+            }
+        });
+        // the tile's contig (contigs start on tile boundaries, so every run that starts in this tile lies in it): one load
+        info = make_uint4(0, 0, 0, 0);
+        if (tid == 0) info = g.tile_info[tile];
+    }
+
+    // registers -> the LDS image, the linear window (clean tile) or the not-ACGT plane in its place (tile with N in reach)
+    __device__ __forceinline__ void store(prf_lds_u4 *vimg, prf_lds_u4 *ximg, prf_lds_u64 *lin, int tid) const {
+        constexpr int nc = NC;
+        const bool hasx = (entry & PRF_LAUNCH_MIXED) != 0;
+        const int np = hasx ? 3 : 2;
+        const int rg = tid >> 6, l = tid & 63;
+        vimg[(0 * RG + rg) * nc + l] = vh0;
+        vimg[(0 * RG + rg + 4) * nc + l] = vh1;
+        vimg[(1 * RG + rg) * nc + l] = vl0;
+        vimg[(1 * RG + rg + 4) * nc + l] = vl1;
+        if (hasx) {
+            ximg[rg * nc + l] = q[0];
+            ximg[(rg + 4) * nc + l] = q[1];
+        } else {
+            static_for<0, NLF>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                lin[tid + i * NTH] = i % 2 == 0 ? ((u64)q[i / 2].x | ((u64)q[i / 2].y << 32)) : ((u64)q[i / 2].z | ((u64)q[i / 2].w << 32));
+            });
+            if (tid < NLT) lin[NLF * NTH + tid] = lt;
+        }
+        const int n_extra = np * RG * extra;
+        static_for<0, NXR>([&](auto rc) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
+            constexpr int r = decltype(rc)::value;
+            const int sx = tid + r * NTH;
+            if (sx < n_extra) {
+                const int p = sx / (RG * extra), erg = (sx / extra) % RG, el = sx % extra;
+                const prf_u32x4 v = (ev[r] >> 1) | (en[r] << 31);
+                const int dst = erg * nc + 64 + el;
+                if (p == 2) ximg[dst] = v;
+                else vimg[p * RG * nc + dst] = v;
+            }
+        });
+    }
+};
+
 template <int NC>
 __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr int nc = NC;
@@ -912,146 +1044,88 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     prf_lds_u32 *bitems = hotw + g.plan.n_exact * 64u + 16u;                // boundary items, plan.n_group_k of them
     prf_lds_u32 *hdr_cnt = (prf_lds_u32 *)(prf_smem + 128);
 
-    const int tid = (int)threadIdx.x;
-    const u32 slot = blockIdx.x;
+    const int tid0 = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     // (when the launch list is one contiguous range of clean tiles -- a contig without N blocks -- the tile index is
     // arithmetic: no dependent load in front of the staging loads)
-    const u32 entry = g.flat_base != ~0u ? g.flat_base + slot : g.launch_list[slot];
+    auto entry_of = [&](u32 sl) -> u32 { return g.flat_base != ~0u ? g.flat_base + sl : g.launch_list[sl]; };
+
+    // ---- once per workgroup ----
+    StageRegs<NC> sr;
+    sr.load(g, entry_of(blockIdx.x), tid0);
+    // boundary items: (motif size, examined-group stride) of every motif size a group task scans
+    for (u32 v = (u32)tid0; v < 8u * g.plan.n_tasks; v += (u32)NTH) {
+        const prf_vtask task = g.plan.tasks[v >> 3];
+        const u32 kk = v & 7u;
+        if (task.kind == 0 && ((task.valid >> kk) & 1u))
+            bitems[(u32)task.item0 + (u32)__builtin_popcount((u32)task.valid & ((1u << kk) - 1u))] = ((u32)task.k0 + kk) | ((u32)task.stride << 16);
+    }
+    {
+        prf_lds_u32 *cof_lds = bitems + g.plan.n_group_k;
+        for (int i = tid0; i < (int)g.plan.cof_words; i += NTH) cof_lds[i] = prf_cof_table.v[i];
+    }
+
+    if (tid0 == 0) {  // the constant part of the tile context
+        TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
+        tcw->H = g.H; tcw->L = g.L; tcw->X = g.X;
+        tcw->E = g.E;
+        tcw->slab_cap = g.slab_cap;
+        tcw->min_repeats = g.min_repeats;
+        tcw->min_span = g.min_span;
+        tcw->lin_off = lin_off;
+        tcw->hotw_off = lin_off + (u32)(2 * LW * sizeof(u64) + MAX_WAVES * REC_PER_WAVE * sizeof(u64));
+        tcw->n_exact = g.plan.n_exact;
+        tcw->k_exact0 = g.plan.k_exact0;
+        tcw->cof_off = tcw->hotw_off + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
+    }
+
+    // Launch slots are handed out dynamically (tiles differ in cost by a factor of three; a fixed stride leaves the last
+    // workgroups running alone for 8 % of the scan): XCD x -- the workgroups b = x mod 8 -- takes the slots = x mod 8, the
+    // first one per workgroup by index, the following ones by a ticket counter of its own (one atomic per tile on eight
+    // separate words; the ticket is drawn at the top of a tile and needed at its end).
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 first_ticket = (gridDim.x - xcd + 7u) >> 3;  // workgroups of this XCD = slots taken without a ticket
+    u64 *ticket_word = g.counters + (PRF_CNT_SHARD0 + xcd * PRF_CNT_SHARD_STRIDE + PRF_SH_TILE_TICKET);
+    prf_lds_u32 *next_words = (prf_lds_u32 *)(prf_smem + 176);  // {next slot, its launch-list entry}
+    u32 slot_next = 0;
+    for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next) {
+    // (opaque per round: what derives from the thread index is recomputed, not carried through the scan's calls in
+    // registers that would have to be spilled)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const u32 entry = sr.entry;
     const bool hasx = (entry & PRF_LAUNCH_MIXED) != 0;
     const u64 tile = entry & ~PRF_LAUNCH_MIXED;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    constexpr int extra = NC - 64;
 
     PRF_STAMP(0);
 #ifdef PRF_STAMPS
-    if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+    if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
-    // ---- 1. stage ----
-    // All global loads of a thread are issued back to back before the first LDS store, so the workgroup pays
-    // one memory round trip (a load -> store loop pays one per iteration: measured 7 k cycles per tile).
+    // ---- 1. stage: the registers loaded during the previous tile's rows phase (or above) -> LDS ----
     {
-        const prf_u32x4 *ph = reinterpret_cast<const prf_u32x4 *>(g.VH), *pL = reinterpret_cast<const prf_u32x4 *>(g.VL),
-                        *px = reinterpret_cast<const prf_u32x4 *>(g.VX);
-        const int np = hasx ? 3 : 2;
-        const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;  // the planes have readable padding in front
-        // H and L bit-sliced planes = 4 slots per thread, X plane (tiles with N) 2 more;
-        // linear window = 8 words per thread + a tail; virtual lanes: one or two slots for the first threads
-        constexpr int NLF = (2 * LW) / NTH;          // full rounds of linear words
-        constexpr int NLT = (2 * LW) - NLF * NTH;    // tail
-        const int rg = tid >> 6, l = tid & 63;       // slot (rg + 4*j, l) of plane p
-        const prf_u32x4 *th = ph + (tile * RG + rg) * 64 + l, *tl = pL + (tile * RG + rg) * 64 + l;
-        const prf_u32x4 vh0 = th[0], vh1 = th[4 * 64], vl0 = tl[0], vl1 = tl[4 * 64];
-        prf_u32x4 vx0 = {0, 0, 0, 0}, vx1 = vx0;
-        if (hasx) {
-            const prf_u32x4 *tx = px + (tile * RG + rg) * 64 + l;
-            vx0 = tx[0];
-            vx1 = tx[4 * 64];
-        }
-        u64 lw[NLF];
-        u64 lt = 0;
-        static_for<0, NLF>([&](auto ic) { lw[decltype(ic)::value] = 0; });
-        if (!hasx) {
-            static_for<0, NLF>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int idx = tid + i * NTH;  // a round may straddle H -> L
-                lw[i] = idx < LW ? g.H[w0 + idx] : g.L[w0 + idx - LW];
-            });
-            if (tid < NLT) lt = g.L[w0 + (NLF * NTH + tid) - LW];
-        }
-        // virtual-lane slots: (plane, row group, first lanes again).  3 planes x 8 row groups x 16 extra lanes (NC = 80,
-        // tile with N in reach) are 384 slots: two rounds of the 256 threads cover every instantiated width.
-        constexpr int NXR = (3 * RG * extra + NTH - 1) / NTH;
-        static_assert(3 * RG * extra <= NXR * NTH, "virtual-lane staging rounds do not cover the image width");
-        prf_u32x4 ev[NXR], en[NXR];
-        const int n_extra = np * RG * extra;
-        static_for<0, NXR>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const int s = tid + r * NTH;
-            ev[r] = prf_u32x4{0, 0, 0, 0};
-            en[r] = ev[r];
-            if (s < n_extra) {
-                const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
-                const u64 i0 = (tile * RG + erg) * 64 + el, i1 = ((tile + 1) * RG + erg) * 64 + el;
-                if (p == 0) {  // (three branches, not a pointer picked from a table: that table would live in scratch memory)
-                    ev[r] = ph[i0];
-                    en[r] = ph[i1];
-                } else if (p == 1) {
-                    ev[r] = pL[i0];
-                    en[r] = pL[i1];
-                } else {
-                    ev[r] = px[i0];
-                    en[r] = px[i1];
-                }
-            }
-        });
-        // the tile's contig (contigs start on tile boundaries, so every run that starts in this tile lies in it): one load
-        uint4 info = make_uint4(0, 0, 0, 0);
-        if (tid == 0) info = g.tile_info[tile];
-        vimg[(0 * RG + rg) * nc + l] = vh0;
-        vimg[(0 * RG + rg + 4) * nc + l] = vh1;
-        vimg[(1 * RG + rg) * nc + l] = vl0;
-        vimg[(1 * RG + rg + 4) * nc + l] = vl1;
-        if (hasx) {
-            ximg[rg * nc + l] = vx0;
-            ximg[(rg + 4) * nc + l] = vx1;
-        } else {
-            static_for<0, NLF>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                lin[tid + i * NTH] = lw[i];
-            });
-            if (tid < NLT) lin[NLF * NTH + tid] = lt;
-        }
-        static_for<0, NXR>([&](auto rc) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
-            constexpr int r = decltype(rc)::value;
-            const int s = tid + r * NTH;
-            if (s < n_extra) {
-                const int p = s / (RG * extra), erg = (s / extra) % RG, el = s % extra;
-                const prf_u32x4 v = (ev[r] >> 1) | (en[r] << 31);
-                const int dst = erg * nc + 64 + el;
-                if (p == 2) ximg[dst] = v;
-                else vimg[p * RG * nc + dst] = v;
-            }
-        });
+        sr.store(vimg, ximg, lin, tid);
         if (tid < 2 * MAX_WAVES + 3) hdr_cnt[tid] = 0;  // list lengths, row count, direct-row count, flushed records
-        // boundary items: (motif size, examined-group stride) of every motif size a group task scans; (k, M) of the exact tasks
-        for (u32 v = (u32)tid; v < 8u * g.plan.n_tasks; v += (u32)NTH) {
-            const prf_vtask task = g.plan.tasks[v >> 3];
-            const u32 kk = v & 7u;
-            if (task.kind == 0 && ((task.valid >> kk) & 1u))
-                bitems[(u32)task.item0 + (u32)__builtin_popcount((u32)task.valid & ((1u << kk) - 1u))] = ((u32)task.k0 + kk) | ((u32)task.stride << 16);
-        }
-        {
-            prf_lds_u32 *cof_lds = bitems + g.plan.n_group_k;
-            for (int i = tid; i < (int)g.plan.cof_words; i += NTH) cof_lds[i] = prf_cof_table.v[i];
-        }
-        if (tid == 0) {
-            TileCtx tc;
-            tc.w0 = tile * PRF_TILE_WORDS - LIN_PRE;
-            tc.xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
-            tc.xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
-            tc.H = g.H; tc.L = g.L; tc.X = g.X;
-            tc.E = g.E;
-            tc.slab = g.slabs + (u64)slot * g.slab_cap;
-            tc.contig = info.x;
-            tc.contig_base = (u64)info.z | ((u64)info.w << 32);
-            tc.tile_base = tile * PRF_TILE;
-            tc.slab_cap = g.slab_cap;
-            tc.min_repeats = g.min_repeats;
-            tc.min_span = g.min_span;
-            tc.lin_off = lin_off;
-            tc.has_lin = hasx ? 0u : 1u;
-            tc.xwin_off = 0u;
-            tc.hotw_off = lin_off + (u32)(2 * LW * sizeof(u64) + MAX_WAVES * REC_PER_WAVE * sizeof(u64));
-            tc.n_exact = g.plan.n_exact;
-            tc.k_exact0 = g.plan.k_exact0;
-            tc.cof_off = tc.hotw_off + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
-            *reinterpret_cast<TileCtx *>(prf_smem) = tc;
+        if (tid == 0) {  // the tile's part of the context (the rest was written once, above)
+            TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
+            tcw->w0 = tile * PRF_TILE_WORDS - LIN_PRE;
+            tcw->xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
+            tcw->xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
+            tcw->slab = g.slabs + (u64)slot * g.slab_cap;
+            tcw->contig = sr.info.x;
+            tcw->contig_base = (u64)sr.info.z | ((u64)sr.info.w << 32);
+            tcw->tile_base = tile * PRF_TILE;
+            tcw->has_lin = hasx ? 0u : 1u;
+            tcw->xwin_off = 0u;
         }
     }
     PRF_STAMP(1);
     __syncthreads();
     PRF_STAMP(2);
+    // the ticket for the tile after this one: drawn here, behind the wait for the staging loads (an atomic in front of it
+    // would be waited for with them: 4 k cycles), used before the last barrier of the tile
+    u64 ticket = 0;
+    if (tid == 0) ticket = atomicAdd(ticket_word, 1ull);
 
     // ---- 2. scan ----
     Emit em;
@@ -1062,7 +1136,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     em.cnt = 0;
     em.flushed = 0;
 #ifdef PRF_STAMPS
-    u64 *task_dbg = g.dbg ? g.dbg + ((u64)blockIdx.x * MAX_WAVES + wave) * 16 : nullptr;
+    u64 *task_dbg = g.dbg ? g.dbg + ((u64)slot * MAX_WAVES + wave) * 16 : nullptr;
 #else
     u64 *task_dbg = nullptr;
 #endif
@@ -1081,19 +1155,26 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         constexpr u32 xwin_off = (u32)SMEM_HDR + (u32)ROW_CAP_LDS * 16u + 4u * 512u * 2u;
         static_assert(xwin_off + LW * 8 <= SMEM_HDR + 2 * RG * NC * 16, "the X window must fit the dead image");
         prf_lds_u64 *xwin = (prf_lds_u64 *)(prf_smem + xwin_off);
+        // (wave-uniform bases + an opaque 32-bit thread offset, as in StageRegs::load)
         const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;
+        const u64 *wh = g.H + w0, *wl = g.L + (w0 - LW), *wx = g.X + (w0 - 2 * LW);
+        u32 ut = (u32)tid;
+        asm volatile("" : "+v"(ut));
         constexpr int NR = (3 * LW + NTH - 1) / NTH;
         u64 v[NR];
         static_for<0, NR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int idx = tid + i * NTH;
-            v[i] = idx < LW ? g.H[w0 + idx] : (idx < 2 * LW ? g.L[w0 + idx - LW] : (idx < 3 * LW ? g.X[w0 + idx - 2 * LW] : 0ull));
+            const u32 idx = ut + (u32)(i * NTH), ob = idx * 8u;
+            if constexpr ((i + 1) * NTH <= LW) v[i] = StageRegs<NC>::ld8(wh, ob);
+            else if constexpr (i * NTH >= LW && (i + 1) * NTH <= 2 * LW) v[i] = StageRegs<NC>::ld8(wl, ob);
+            else if constexpr (i * NTH >= 2 * LW && (i + 1) * NTH <= 3 * LW) v[i] = StageRegs<NC>::ld8(wx, ob);
+            else v[i] = idx < (u32)LW ? StageRegs<NC>::ld8(wh, ob) : (idx < 2u * LW ? StageRegs<NC>::ld8(wl, ob) : (idx < 3u * LW ? StageRegs<NC>::ld8(wx, ob) : 0ull));
         });
         static_for<0, NR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int idx = tid + i * NTH;
-            if (idx < 2 * LW) lin[idx] = v[i];
-            else if (idx < 3 * LW) xwin[idx - 2 * LW] = v[i];
+            const u32 idx = ut + (u32)(i * NTH);
+            if (idx < 2u * LW) lin[idx] = v[i];
+            else if (idx < 3u * LW) xwin[idx - 2u * LW] = v[i];
         });
         if (tid == 0) {
             TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
@@ -1113,21 +1194,35 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         if (n_flags)
             atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
     }
+    if (tid == 0) {  // the next slot and its entry, for everybody behind the barrier
+        const u32 sn = (first_ticket + (u32)ticket) * 8u + xcd;
+        next_words[0] = sn;
+        next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
+    }
     PRF_STAMP(5);
     __syncthreads();
     PRF_STAMP(6);
+    slot_next = (u32)__builtin_amdgcn_readfirstlane((int)next_words[0]);
+    const u32 entry_next = next_words[1];
+
+    // the next tile's staging data: loads issued now, consumed at the top of the loop
+    // (unconditional: the registers are dead from the stage to here, not carried around the loop)
+    sr.load(g, entry_next, tid);
 
     // ---- 4. the tile's rows, sorted by (start, end), into its slab: [rows written directly, unsorted][the LDS list, sorted].
     // Rank of a row = number of rows of the list with a smaller key; keys are distinct ((start, end) pairs never collide
     // between motif sizes).
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
+    // (the slab through the kernel argument, not through the pointer in the LDS context: that one is generic, and a FLAT
+    // store counts as an LDS operation too -- the next LDS wait would sit behind the prefetch loads just issued)
+    prf_hit_dev *slab = g.slabs + (u64)slot * g.slab_cap;
     u32 n_listed = *smem_row_cnt();
     u32 n_direct = *smem_direct_cnt();
     if (n_direct && n_listed + n_direct <= (u32)ROW_CAP_LDS && n_direct <= tc.slab_cap) {
         // Rows that went straight to the slab (a wave emptied its record list in the middle of the scan) and still fit the
         // list: read them back and sort them with the others -- the tile stays sorted.
         if ((u32)tid < n_direct) {
-            const prf_hit_dev h = tc.slab[tid];
+            const prf_hit_dev h = slab[tid];
             const u64 a = h.start + tc.contig_base, end = h.end + tc.contig_base, span = end - a;
             smem_row_keys()[n_listed + tid] = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
             smem_row_ks()[n_listed + tid] = h.k;
@@ -1182,7 +1277,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
             h.end = end - tc.contig_base;
             h.k = kk;
             h.contig = tc.contig;
-            tc.slab[dst] = h;
+            slab[dst] = h;
         }
     }
     if (tid == 0) {
@@ -1197,8 +1292,10 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     }
     PRF_STAMP(7);
 #ifdef PRF_STAMPS
-    if (g.dbg && lane == 0) g.dbg[((u64)blockIdx.x * MAX_WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+    if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
+    __syncthreads();  // the header, the row list and the image region are rewritten for the next tile
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1462,10 +1559,19 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
 
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
     if (args.n_launch == 0) return hipSuccess;
-    const dim3 grid(args.n_launch), block(NTH);
     // PRF_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, to measure the scan at a lower occupancy
     static const u32 lds_pad = getenv("PRF_LDS_PAD") ? (u32)atoi(getenv("PRF_LDS_PAD")) : 0u;
     const u32 lds = args.plan.lds_bytes + lds_pad;
+    // persistent workgroups: as many as are resident at once (LDS- and register-bound: 4 per CU at most)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu = prop.multiProcessorCount;
+    }
+    const u32 per_cu = std::max(1u, std::min(4u, (160u * 1024u) / std::max(1u, lds)));
+    const dim3 grid(std::min(args.n_launch, per_cu * (u32)n_cu)), block(NTH);
     switch (args.plan.nc) {
         case 72: hipLaunchKernelGGL((prf_vscan_kernel<72>), grid, block, lds, s, args); break;
         case 80: hipLaunchKernelGGL((prf_vscan_kernel<80>), grid, block, lds, s, args); break;
