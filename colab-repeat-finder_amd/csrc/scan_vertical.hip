@@ -997,6 +997,16 @@ struct StageRegs {
         if (tid == 0) info = g.tile_info[tile];
     }
 
+    __device__ __forceinline__ void clear() {
+        const prf_u32x4 z = {0, 0, 0, 0};
+        vh0 = vh1 = vl0 = vl1 = z;
+        static_for<0, NLF / 2>([&](auto ic) { q[decltype(ic)::value] = z; });
+        lt = 0;
+        static_for<0, NXR>([&](auto rc) { ev[decltype(rc)::value] = en[decltype(rc)::value] = z; });
+        info = make_uint4(0, 0, 0, 0);
+        entry = 0;
+    }
+
     // registers -> the LDS image, the linear window (clean tile) or the not-ACGT plane in its place (tile with N in reach)
     __device__ __forceinline__ void store(prf_lds_u4 *vimg, prf_lds_u4 *ximg, prf_lds_u64 *lin, int tid) const {
         constexpr int nc = NC;
@@ -1206,8 +1216,9 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const u32 entry_next = next_words[1];
 
     // the next tile's staging data: loads issued now, consumed at the top of the loop
-    // (unconditional: the registers are dead from the stage to here, not carried around the loop)
-    sr.load(g, entry_next, tid);
+    // (every register is written on both paths: dead from the stage to here, not carried around the loop)
+    if (slot_next < g.n_launch) sr.load(g, entry_next, tid);
+    else sr.clear();
 
     // ---- 4. the tile's rows, sorted by (start, end), into its slab: [rows written directly, unsorted][the LDS list, sorted].
     // Rank of a row = number of rows of the list with a smaller key; keys are distinct ((start, end) pairs never collide
