@@ -1197,14 +1197,12 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
 
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's LDS list, or nothing ----
     u32 n_flags = verify_all((prf_lds_cu64 *)recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (u32)tid, task_dbg);
-    // statistics: candidates looked at = (stream, exact task) flags + group-task records
-    for (int o = 32; o > 0; o >>= 1) n_flags += __shfl_xor(n_flags, o, 64);
-    if (lane == 0) {
-        if (wave == 0) n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
+    if (tid == 0) {
+        // statistics: candidates looked at = (stream, exact task) flags (thread 0 holds their number) + group-task records
+        n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
         if (n_flags)
             atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
-    }
-    if (tid == 0) {  // the next slot and its entry, for everybody behind the barrier
+        // the next slot and its entry, for everybody behind the barrier
         const u32 sn = (first_ticket + (u32)ticket) * 8u + xcd;
         next_words[0] = sn;
         next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
@@ -1250,9 +1248,13 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         // list, the shares are added up across the P lanes.  Dependent LDS round trips are what this phase costs (~500 cycles
         // each with the other workgroups' scans on the CU): the row's own key, end and motif size and the first 32 keys of
         // the lane's share are ONE batch of reads; the shares are added with DPP moves, not LDS shuffles.
-        const u32 lg = n_sorted > 128u ? 0u : (n_sorted > 64u ? 1u : (n_sorted > 32u ? 2u : (n_sorted > 16u ? 3u : 4u)));
+        // (P <= 8: eight reads of a lane, 4 P keys apart, stay inside the 256 padded keys)
+        const u32 lg = n_sorted > 128u ? 0u : (n_sorted > 64u ? 1u : (n_sorted > 32u ? 2u : 3u));
         const u32 P = 1u << lg, row = (u32)tid >> lg, part = (u32)tid & (P - 1u);
         prf_lds_u32 *keys = smem_row_keys();
+        // the list is padded to its capacity with the largest key: no bounds test per key in the loop below
+        if ((u32)tid >= n_sorted) keys[tid] = 0xFFFFFFFFu;
+        __syncthreads();  // (n_sorted is the same for every thread)
         typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
         prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)keys;
         const u32 r = row < n_sorted ? row : 0u;  // (lanes without a row read row 0: harmless)
@@ -1261,18 +1263,19 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         const u32 kk = smem_row_ks()[r];
         u32 rank = 0;
         // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, eight reads in flight
-        // (reads past the list stay inside the dead image)
         for (u32 c0 = part; 4u * c0 < n_sorted; c0 += 8u * P) {
             prf_u32x4 v[8];
 #pragma unroll
             for (u32 j = 0; j < 8u; j++) v[j] = k4[c0 + j * P];
+            // (all eight reads in flight before the first compare: left alone the compiler issues them two at a time, a
+            // round trip per pair, to save registers it does not need here)
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
             for (u32 j = 0; j < 8u; j++) {
-                const u32 b0 = 4u * (c0 + j * P);
-                rank += (b0 < n_sorted && v[j].x < mine) ? 1u : 0u;
-                rank += (b0 + 1u < n_sorted && v[j].y < mine) ? 1u : 0u;
-                rank += (b0 + 2u < n_sorted && v[j].z < mine) ? 1u : 0u;
-                rank += (b0 + 3u < n_sorted && v[j].w < mine) ? 1u : 0u;
+                rank += v[j].x < mine ? 1u : 0u;  // (keys past the list are 0xFFFFFFFF: never smaller)
+                rank += v[j].y < mine ? 1u : 0u;
+                rank += v[j].z < mine ? 1u : 0u;
+                rank += v[j].w < mine ? 1u : 0u;
             }
         }
         // sum over the P adjacent lanes of a row (wave-uniform P): xor 1, xor 2 by quad permutes; after those all lanes of a
@@ -1280,7 +1283,6 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         if (P >= 2u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0xB1, 0xF, 0xF, true);
         if (P >= 4u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x4E, 0xF, 0xF, true);
         if (P >= 8u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x141, 0xF, 0xF, true);
-        if (P >= 16u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x140, 0xF, 0xF, true);
         const u32 dst = n_direct + rank;
         if (row < n_sorted && part == 0 && dst < tc.slab_cap) {
             prf_hit_dev h;
