@@ -971,19 +971,22 @@ struct StageRegs {
             });
             if (tid < NLT) lt = ld8(wl, o8 + (u32)(NLF * NTH * 8));
         }
-        const int n_extra = np * RG * extra;
+        const u32 n_extra = (u32)(np * RG * extra);
         static_for<0, NXR>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            const int sx = (int)ut + r * NTH;
+            const u32 sx = ut + (u32)(r * NTH);
             ev[r] = prf_u32x4{0, 0, 0, 0};
             en[r] = ev[r];
             if (sx < n_extra) {
-                const int p = sx / (RG * extra), erg = (sx / extra) % RG, el = sx % extra;
-                const u32 i0 = (u32)(erg * 64 + el) * 16u, i1 = i0 + (u32)(RG * 64) * 16u;  // the same slot of the next tile
-                if (p == 0) {  // (three branches, not a pointer picked from a table: that table would live in scratch memory)
+                // the plane is the same for a whole wave (RG * extra is a multiple of 64): a scalar select of the base
+                static_assert((RG * extra) % 64 == 0, "virtual-lane staging: one plane per wave");
+                const u32 pw = (u32)__builtin_amdgcn_readfirstlane((int)(sx / (u32)(RG * extra)));
+                const u32 erg = (sx / (u32)extra) % (u32)RG, el = sx % (u32)extra;
+                const u32 i0 = (erg * 64u + el) * 16u, i1 = i0 + (u32)(RG * 64) * 16u;  // the same slot of the next tile
+                if (pw == 0) {  // (three branches, not a selected pointer: the compiler makes a table in scratch memory of that)
                     ev[r] = ld16(ph, i0);
                     en[r] = ld16(ph, i1);
-                } else if (p == 1) {
+                } else if (pw == 1) {
                     ev[r] = ld16(pL, i0);
                     en[r] = ld16(pL, i1);
                 } else {
@@ -1027,14 +1030,14 @@ struct StageRegs {
             });
             if (tid < NLT) lin[NLF * NTH + tid] = lt;
         }
-        const int n_extra = np * RG * extra;
+        const u32 n_extra = (u32)(np * RG * extra);
         static_for<0, NXR>([&](auto rc) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
             constexpr int r = decltype(rc)::value;
-            const int sx = tid + r * NTH;
+            const u32 sx = (u32)tid + (u32)(r * NTH);
             if (sx < n_extra) {
-                const int p = sx / (RG * extra), erg = (sx / extra) % RG, el = sx % extra;
+                const u32 p = sx / (u32)(RG * extra), erg = (sx / (u32)extra) % (u32)RG, el = sx % (u32)extra;
                 const prf_u32x4 v = (ev[r] >> 1) | (en[r] << 31);
-                const int dst = erg * nc + 64 + el;
+                const u32 dst = erg * (u32)nc + 64u + el;
                 if (p == 2) ximg[dst] = v;
                 else vimg[p * RG * nc + dst] = v;
             }
@@ -1210,8 +1213,9 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     PRF_STAMP(5);
     __syncthreads();
     PRF_STAMP(6);
-    slot_next = (u32)__builtin_amdgcn_readfirstlane((int)next_words[0]);
-    const u32 entry_next = next_words[1];
+    const u64 nw = *(prf_lds_cu64 *)next_words;  // (one read)
+    slot_next = (u32)__builtin_amdgcn_readfirstlane((int)(u32)nw);
+    const u32 entry_next = (u32)(nw >> 32);
 
     // the next tile's staging data: loads issued now, consumed at the top of the loop
     // (every register is written on both paths: dead from the stage to here, not carried around the loop)
