@@ -51,6 +51,7 @@ struct prf_vplan {
     u32 n_group_k;                              // motif sizes scanned by group tasks (boundary items of a tile)
     u32 n_exact;                                // exact tasks: motif sizes k_exact0 .. k_exact0 + n_exact - 1 (item0 = k - k_exact0)
     u32 k_exact0;
+    u32 ticket_wave;                            // the wave whose first lane draws the workgroup's next launch slot (it waits for the atomic)
 };
 
 // everything the fused kernel needs (passed by value)

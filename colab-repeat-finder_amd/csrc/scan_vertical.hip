@@ -1136,9 +1136,12 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     __syncthreads();
     PRF_STAMP(2);
     // the ticket for the tile after this one: drawn here, behind the wait for the staging loads (an atomic in front of it
-    // would be waited for with them: 4 k cycles), used before the last barrier of the tile
+    // would be waited for with them: 4 k cycles), used before the last barrier of the tile.  The compiler turns the
+    // returning atomic into a wave-aggregated one and waits for its value on the spot: the plan deals it to the wave
+    // with the least other work.
     u64 ticket = 0;
-    if (tid == 0) ticket = atomicAdd(ticket_word, 1ull);
+    const bool ticket_thread = tid == (int)(g.plan.ticket_wave * 64u);  // (the plan's least loaded wave)
+    if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
 
     // ---- 2. scan ----
     Emit em;
@@ -1205,7 +1208,8 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
         if (n_flags)
             atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
-        // the next slot and its entry, for everybody behind the barrier
+    }
+    if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
         const u32 sn = (first_ticket + (u32)ticket) * 8u + xcd;
         next_words[0] = sn;
         next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
@@ -1495,7 +1499,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
             it.t.stride = 1;
-            it.cost = 240 + 15 * (u32)M;  // measured (stamps build): 3.3 k (M = 6) ... 4.5 k (M = 14) cycles per exact task
+            // measured (stamps build, 4 workgroups per CU, units of 8.5 cycles): 2.8 k cycles for M = 6 (one operation per start
+            // word), 4.0 - 4.4 k for M = 7 .. 14 (two)
+            it.cost = M <= 6 ? 250u + 13u * (u32)M : 440u + 5u * (u32)M;
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
@@ -1516,7 +1522,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            it.cost = stride == 1 ? 740u : (stride == 2 ? 480u : 300u);  // measured: 7.4 k / 4.8 k / 3.0 k cycles
+            // measured: 6.3 k / 4.2 k / 3.9 k cycles with 8 sizes, 2.4 k for stride 4 with 3
+            it.cost = (stride == 1 ? 500u : (stride == 2 ? 260u : 200u)) + 30u * (u32)__builtin_popcount(valid);
             items.push_back(it);
             reach = std::max<u32>(reach, 24 + k0 + 15);
             covered_to = k0 + 8;
@@ -1529,11 +1536,24 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     std::vector<u32> load(nw, 0);
     std::vector<Item> sorted = items;
     std::stable_sort(sorted.begin(), sorted.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+    // The ticket for the workgroup's next launch slot is an atomic whose value the compiler waits for on the spot (~3 k
+    // cycles with a thousand workgroups drawing): it is dealt like a task, to the wave with the least other work -- or to
+    // a wave without tasks, if there is one.  (Tried and dropped: the waves of a workgroup pulling tasks from one list
+    // through an LDS counter at run time -- every wave's scan got 2-3 k cycles longer.)
+    constexpr u32 TICKET_COST = 350;
+    bool ticket_dealt = nw < (u32)PRF_VMAX_WAVES;
+    plan->ticket_wave = nw < (u32)PRF_VMAX_WAVES ? nw : 0;
     for (const Item &it : sorted) {
+        if (!ticket_dealt && it.cost <= TICKET_COST) {
+            plan->ticket_wave = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[plan->ticket_wave] += TICKET_COST;
+            ticket_dealt = true;
+        }
         const u32 w = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
         bins[w].push_back(it);
         load[w] += it.cost;
     }
+    if (!ticket_dealt) plan->ticket_wave = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
     plan->n_waves = nw;
     plan->n_tasks = 0;
     plan->n_group_k = 0;
