@@ -1539,7 +1539,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     // The ticket for the workgroup's next launch slot is an atomic whose value the compiler waits for on the spot (~3 k
     // cycles with a thousand workgroups drawing): it is dealt like a task, to the wave with the least other work -- or to
     // a wave without tasks, if there is one.  (Tried and dropped: the waves of a workgroup pulling tasks from one list
-    // through an LDS counter at run time -- every wave's scan got 2-3 k cycles longer.)
+    // through an LDS counter at run time -- every wave's scan got 2-3 k cycles longer; the stride-1 group task cut in two
+    // halves of four sizes -- a half costs three quarters of the whole, its four blocks are LDS latency, not arithmetic.)
     constexpr u32 TICKET_COST = 350;
     bool ticket_dealt = nw < (u32)PRF_VMAX_WAVES;
     plan->ticket_wave = nw < (u32)PRF_VMAX_WAVES ? nw : 0;
