@@ -2,10 +2,11 @@
 //
 // Host-side shape of one scan (what replaces the body of the reference's detect_repeats(),
 // perfect_repeat_finder.py:33-81):
-//   fused path (kmax <= 480): ONE kernel launch -- scan + verify + rows compacted into one array + counters posted
-//   to mapped host memory; the host polls the scan's serial number there.  Generic path (any k): memset counters ->
-//   candidate kernel -> verify kernel -> copy back two counters.  Either way: grow buffers and repeat on overflow,
-//   then copy the rows back (sorted by (contig, start, end) as the reference sorts its dict, :81).
+//   fused path (kmax <= 480): two launches -- the scan kernel (persistent workgroups: scan + verify + the rows of every
+//   tile sorted into its slab) and the row gather (slabs -> ONE array sorted by (contig, start, end), as the reference
+//   sorts its dict, :81; its last workgroup posts the counters to mapped host memory, where the host polls the scan's
+//   serial number).  Generic path (any k): memset counters -> candidate kernel -> verify kernel -> copy back two
+//   counters -> host sort.  Either way: grow buffers and repeat on overflow, then copy the rows back.
 // Everything runs on the context's own HIP stream; timings are HIP events on that stream.
 #include <hip/hip_runtime.h>
 
