@@ -52,6 +52,9 @@ struct prf_vplan {
     u32 n_exact;                                // exact tasks: motif sizes k_exact0 .. k_exact0 + n_exact - 1 (item0 = k - k_exact0)
     u32 k_exact0;
     u32 ticket_wave;                            // the wave whose first lane draws the workgroup's next launch slot (it waits for the atomic)
+    u32 slack_waves;                            // bit w: wave w's scan work is < 90 % of the busiest wave's
+    u32 prio;                                   // issue priorities (s_setprio), 2 bits each: stage | scan, busy wave << 2 | scan, slack
+                                                // wave << 4 | verify, flag waves << 6 | verify, record waves << 8 | rows << 10
 };
 
 // everything the fused kernel needs (passed by value)

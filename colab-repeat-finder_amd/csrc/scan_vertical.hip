@@ -898,6 +898,13 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, 
 #endif
 }
 
+__device__ __forceinline__ void set_prio(u32 p) {  // (s_setprio takes an immediate; p is wave-uniform)
+    if (p == 0u) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 // Grid: persistent workgroups, 4 per CU (or one per entry of the launch list if that is fewer): workgroup b takes the launch
 // slots b, b + gridDim, ...  (tiles in position order; slabs and counts are indexed by slot, so the order of execution does
 // not show in the output).  The global loads of the NEXT tile's staging data are issued at the start of the rows phase of
@@ -1064,6 +1071,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     auto entry_of = [&](u32 sl) -> u32 { return g.flat_base != ~0u ? g.flat_base + sl : g.launch_list[sl]; };
 
     // ---- once per workgroup ----
+    set_prio(g.plan.prio & 3u);
     StageRegs<NC> sr;
     sr.load(g, entry_of(blockIdx.x), tid0);
     // boundary items: (motif size, examined-group stride) of every motif size a group task scans
@@ -1116,6 +1124,7 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
     // ---- 1. stage: the registers loaded during the previous tile's rows phase (or above) -> LDS ----
+    set_prio(g.plan.prio & 3u);
     {
         sr.store(vimg, ximg, lin, tid);
         if (tid < 2 * MAX_WAVES + 3) hdr_cnt[tid] = 0;  // list lengths, row count, direct-row count, flushed records
@@ -1144,6 +1153,9 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
 
     // ---- 2. scan ----
+    // Issue priority (plan.prio): each SIMD hosts waves of four workgroups in different phases, about a third busy; the
+    // phases that are chains of dependent LDS round trips go first, the scan takes the slots that are left.
+    set_prio(((g.plan.slack_waves >> wave) & 1u) ? (g.plan.prio >> 4) & 3u : (g.plan.prio >> 2) & 3u);
     Emit em;
     em.recs = recs + wave * REC_PER_WAVE;
     em.all_recs = (prf_lds_cu64 *)recs;
@@ -1202,7 +1214,10 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     PRF_STAMP(4);
 
     // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's LDS list, or nothing ----
+    // (the record waves are the critical path of this phase, the flag waves wait for them at the barrier below)
+    set_prio(wave < MAX_WAVES / 2 ? (g.plan.prio >> 6) & 3u : (g.plan.prio >> 8) & 3u);
     u32 n_flags = verify_all((prf_lds_cu64 *)recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (u32)tid, task_dbg);
+    set_prio((g.plan.prio >> 10) & 3u);
     if (tid == 0) {
         // statistics: candidates looked at = (stream, exact task) flags (thread 0 holds their number) + group-task records
         n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
@@ -1555,6 +1570,19 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
         load[w] += it.cost;
     }
     if (!ticket_dealt) plan->ticket_wave = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+    {
+        // default: the short, latency-bound phases (stage, the record waves of the verify phase, rows) at priority 2, the scan
+        // (long, plenty of independent arithmetic) and the flag waves (they wait at the barrier anyway) at 0.  Measured on
+        // the default workload (tools/prio_sweep.sh, gpurun_out/prio_sweep*.txt): 0.775 ms without priorities, 0.748-0.757
+        // with any setting that raises records and rows; random sequence (few candidates) is indifferent.
+        // PRF_PRIO (diagnostic) overrides.
+        static const u32 prio_cfg = getenv("PRF_PRIO") ? (u32)strtoul(getenv("PRF_PRIO"), nullptr, 0) : 0xA02u;
+        plan->prio = prio_cfg;
+        const u32 busiest = *std::max_element(load.begin(), load.end());
+        plan->slack_waves = 0;
+        for (u32 w = 0; w < (u32)PRF_VMAX_WAVES; w++)
+            if (w >= nw || 10u * load[w] < 9u * busiest) plan->slack_waves |= 1u << w;
+    }
     plan->n_waves = nw;
     plan->n_tasks = 0;
     plan->n_group_k = 0;
