@@ -1031,19 +1031,18 @@ int prf_last_hits_packed_to_device(prf_ctx *c, const prf_genome *g, void *dst, u
         return fail(PRF_EINVAL, "the packed row buffer holds %llu rows, the scan found %llu", (unsigned long long)capacity_rows,
                     (unsigned long long)c->last_nhits);
     u64 *words = (u64 *)dst;
-    u64 *side_cnt = c->d_counters + PRF_CNT_CAND;  // (a spare device word: the generic path's counters are idle here)
+    // (a spare device word: the generic path's counters are idle here; spare pinned words behind the counter block,
+    // written by the device)
+    u64 *side_cnt = c->d_counters + PRF_CNT_CAND;
     HIPCHK(hipMemsetAsync(side_cnt, 0, sizeof(u64), c->stream));
-    HIPCHK(prf_launch_pack_rows(c->stream, c->last_rows, c->last_nhits, g->d_base, words, capacity_rows, side_capacity, side_cnt));
-    u64 *stage = c->h_counters + PRF_CNT_N + 2;  // spare pinned words behind the counter block
-    HIPCHK(hipMemcpyAsync(stage, side_cnt, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    volatile u64 *stage = c->h_counters + PRF_CNT_N + 2;
+    HIPCHK(prf_launch_pack_rows(c->stream, c->last_rows, c->last_nhits, g->d_base, words, capacity_rows, side_capacity, side_cnt,
+                                c->h_counters_dev + PRF_CNT_N + 2));
     HIPCHK(hipStreamSynchronize(c->stream));
     const u64 n_side = stage[0];
     if (n_side > side_capacity)
         return fail(PRF_EINVAL, "the side list holds %llu rows, %llu rows are longer than 65534", (unsigned long long)side_capacity,
                     (unsigned long long)n_side);
-    stage[1] = c->last_nhits | (n_side << 40);
-    HIPCHK(hipMemcpyAsync(words + capacity_rows, stage + 1, sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     return PRF_OK;
 }
 

@@ -39,4 +39,4 @@ hipError_t prf_launch_verify(hipStream_t s, const prf_planes &pl, const u64 *can
 
 hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sink);
 hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, const u64 *contig_base, u64 *dst, u64 cap, u64 side_cap,
-                                u64 *side_cnt);
+                                u64 *side_cnt, u64 *host_word);

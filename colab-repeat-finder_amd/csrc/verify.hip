@@ -84,9 +84,17 @@ __global__ __launch_bounds__(256) void prf_pack_rows_kernel(const prf_hit_dev *_
     }
 }
 
+// behind the pack kernel on the same stream: the count word (rows | long rows << 40) goes into the buffer, the number of long
+// rows to mapped host memory -- no copy calls, one wait on the host
+__global__ void prf_pack_finish_kernel(u64 *side_cnt, u64 n, u64 *count_word, u64 *host_word) {
+    const u64 c = *side_cnt;
+    *count_word = n | (c << 40);
+    *host_word = c;
+}
+
 hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, const u64 *contig_base, u64 *dst, u64 cap, u64 side_cap,
-                                u64 *side_cnt) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(prf_pack_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, rows, n, contig_base, dst, cap, side_cap, side_cnt);
+                                u64 *side_cnt, u64 *host_word) {
+    if (n) hipLaunchKernelGGL(prf_pack_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, rows, n, contig_base, dst, cap, side_cap, side_cnt);
+    hipLaunchKernelGGL(prf_pack_finish_kernel, dim3(1), dim3(1), 0, s, side_cnt, n, dst + cap, host_word);
     return hipGetLastError();
 }
