@@ -580,7 +580,8 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     if (min_repeats < 1) return fail(PRF_EINVAL, "min_repeats is set to %u. It must be at least 1.", min_repeats);
     if (min_span < 1) return fail(PRF_EINVAL, "min_span is set to %u. It must be at least 1.", min_span);
     if (min_repeats < 2)
-        return fail(PRF_EUNSUPPORTED, "min_repeats == 1 is outside the closed form implemented on the GPU (SURVEY 3.4)");
+        return fail(PRF_EUNSUPPORTED, "min_repeats == 1 is outside the closed form of the packed kernels: use prf_scan() or "
+                                      "prf_scan_literal() on the sequence bytes (scan_literal.hip)");
     if (kmax > g->kmax_hint)
         return fail(PRF_EUNSUPPORTED, "max_motif_size %u exceeds the kmax_hint %u this genome was packed with", kmax,
                     g->kmax_hint);
@@ -824,8 +825,160 @@ int prf_scan_genome(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kma
     }
 }
 
+// ---- the literal lane (scan_literal.hip): regimes outside the closed form ----
+// One sequence at a time, straight from its ASCII bytes (upper-cased on the device): one thread per (position, motif size)
+// evaluates the reference's flush call as written; the host keeps the shortest motif per (start, end), which is what the
+// reference's dictionary holds at the end (utils/perfect_repeat_tracker.py:93-101), and sorts like reference :81.
+namespace {
+struct dev_free {
+    void *p = nullptr;
+    ~dev_free() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
+                       u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
+    const u64 L = ct.len;
+    if (L && !ct.ascii) return fail(PRF_EINVAL, "prf_scan_literal: NULL sequence");
+    if (L >= (1ull << 40)) return fail(PRF_EUNSUPPORTED, "prf_scan_literal: input too large (2^40 positions)");
+    if (stop > L) stop = L;
+    dev_free seq, rows;
+    HIPCHK(hipMalloc(&seq.p, L + 16));
+    if (L) HIPCHK(hipMemcpyAsync(seq.p, ct.ascii, L, hipMemcpyHostToDevice, c->stream));
+    u64 cap = L / 16 + 4096;
+    u64 *h = c->h_counters;
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(hipMalloc(&rows.p, cap * sizeof(prf_hit_dev)));
+        HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_counters + PRF_CNT_BADPOS, 0xFF, sizeof(u64), c->stream));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        if (attempt == 0) HIPCHK(prf_launch_lit_upper(c->stream, (uint8_t *)seq.p, L, c->d_counters + PRF_CNT_BADPOS));
+        HIPCHK(prf_launch_lit_events(c->stream, (const uint8_t *)seq.p, L, kmin, kmax, min_repeats, min_span, stop, contig_index,
+                                     (prf_hit_dev *)rows.p, cap, c->d_counters));
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(hipMemcpyAsync(h, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+        *ms += t;
+        *launches += attempt == 0 ? 2 : 1;
+        if (h[PRF_CNT_BADPOS] != ~0ull)
+            return fail(PRF_ESYMBOL,
+                        "unsupported symbol at contig %u position %llu: only letters are accepted (A, C, G, T, N and -- as ordinary "
+                        "symbols, like the reference -- any other letter, in either case); libprf refuses other bytes instead of guessing",
+                        contig_index, (unsigned long long)h[PRF_CNT_BADPOS]);
+        if (h[PRF_CNT_CAND])
+            return fail(PRF_EINDEX, "string index out of range");  // the message of Python's IndexError (tracker :87)
+        const u64 n = h[PRF_CNT_HITS];
+        if (n <= cap) {
+            const size_t at = rows_out.size();
+            rows_out.resize(at + n);
+            static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
+            if (n) {
+                HIPCHK(hipMemcpyAsync(rows_out.data() + at, rows.p, n * sizeof(prf_hit), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
+            std::sort(rows_out.begin() + at, rows_out.end(), [](const prf_hit &a, const prf_hit &b) {
+                if (a.start != b.start) return a.start < b.start;
+                if (a.end != b.end) return a.end < b.end;
+                return a.k < b.k;
+            });
+            auto last = std::unique(rows_out.begin() + at, rows_out.end(),
+                                    [](const prf_hit &a, const prf_hit &b) { return a.start == b.start && a.end == b.end; });
+            rows_out.erase(last, rows_out.end());
+            return PRF_OK;
+        }
+        if (attempt >= 2) return fail(PRF_EHIP, "prf_scan_literal: the row count changed between two runs");
+        (void)hipFree(rows.p);
+        rows.p = nullptr;
+        cap = n;
+    }
+}
+
+static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, const u64 *stops, u32 kmin, u32 kmax, u32 min_repeats,
+                        u32 min_span, prf_hits *out, prf_scan_stats *stats) {
+    if (!c) return fail(PRF_EINVAL, "prf_scan_literal: NULL context");
+    if (out) { out->rows = nullptr; out->n = 0; }
+    if (n_contigs < 0 || (n_contigs && !contigs)) return fail(PRF_EINVAL, "prf_scan_literal: bad contig array");
+    // same conditions, same wording as the reference's ValueErrors (perfect_repeat_finder.py:23-30)
+    if (kmin < 1) return fail(PRF_EINVAL, "min_motif_size is set to %u. It must be at least 1.", kmin);
+    if (kmax < kmin) return fail(PRF_EINVAL, "max_motif_size is set to %u. It must be at least min_motif_size.", kmax);
+    if (min_repeats < 1) return fail(PRF_EINVAL, "min_repeats is set to %u. It must be at least 1.", min_repeats);
+    if (min_span < 1) return fail(PRF_EINVAL, "min_span is set to %u. It must be at least 1.", min_span);
+    if (kmax > 60000) return fail(PRF_EUNSUPPORTED, "max_motif_size %u > 60000", kmax);
+    if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
+    if (c->async_n) return fail(PRF_EINVAL, "prf_scan_literal: pipelined scans are in flight on this context");
+    HIPCHK(hipSetDevice(c->dev));
+    std::vector<prf_hit> rows;
+    float ms = 0;
+    u32 launches = 0;
+    u64 positions = 0;
+    for (int i = 0; i < n_contigs; i++) {
+        prf_contig w = contigs[i];
+        u64 lo = 0;
+        if (!stops && w.len) {
+            // prf_scan: the whole of reference detect_repeats() without an interval, whose :40-46 drop the N at both ends
+            // first -- not a no-op in this regime, the rows depend on where the sequence begins and ends
+            if (!w.ascii) return fail(PRF_EINVAL, "prf_scan: NULL sequence");
+            u64 hi = w.len;
+            while (lo < hi && (w.ascii[lo] | 0x20) == 'n') lo++;
+            while (hi > lo && (w.ascii[hi - 1] | 0x20) == 'n') hi--;
+            w.ascii += lo;
+            w.len = hi - lo;
+        }
+        const size_t at = rows.size();
+        const int rc = literal_one(c, w, (u32)i, kmin, kmax, min_repeats, min_span, stops ? stops[i] : w.len, rows, &ms, &launches);
+        if (rc) return rc;
+        for (size_t r = at; r < rows.size(); r++) {
+            rows[r].start += lo;
+            rows[r].end += lo;
+        }
+        positions += contigs[i].len;
+    }
+    c->last_nhits = 0;  // the rows of this lane live on the host only
+    c->last_rows = nullptr;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->scan_ms = stats->phase1_ms = ms;
+        stats->positions = positions;
+        stats->packed_bytes = positions;  // this lane reads the bytes themselves
+        stats->n_candidates = stats->n_hits = rows.size();
+        stats->n_launches = launches;
+        stats->path = 2;
+    }
+    if (!out || rows.empty()) return PRF_OK;
+    prf_hit *r = (prf_hit *)malloc(rows.size() * sizeof(prf_hit));
+    if (!r) return fail(PRF_ENOMEM, "prf_scan_literal: cannot allocate %zu rows", rows.size());
+    memcpy(r, rows.data(), rows.size() * sizeof(prf_hit));
+    out->rows = r;
+    out->n = rows.size();
+    return PRF_OK;
+}
+
+int prf_scan_literal(prf_ctx *c, const prf_contig *contig, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,
+                     uint64_t stop, prf_hits *out, prf_scan_stats *stats) {
+    try {
+        if (!contig) return fail(PRF_EINVAL, "prf_scan_literal: NULL contig");
+        const u64 stop_ = stop;
+        return literal_impl(c, contig, 1, &stop_, kmin, kmax, min_repeats, min_span, out, stats);
+    } catch (const std::bad_alloc &) {
+        return fail(PRF_ENOMEM, "prf_scan_literal: out of host memory");
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_scan_literal: unexpected exception");
+    }
+}
+
 int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
              uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats) {
+    if (min_repeats == 1) {  // outside the closed form of the packed kernels: the literal lane, contig by contig
+        try {
+            return literal_impl(c, contigs, n_contigs, nullptr, kmin, kmax, min_repeats, min_span, out, stats);
+        } catch (const std::bad_alloc &) {
+            return fail(PRF_ENOMEM, "prf_scan: out of host memory");
+        } catch (...) {
+            return fail(PRF_EHIP, "prf_scan: unexpected exception");
+        }
+    }
     prf_genome *g = nullptr;
     int rc = prf_genome_load(c, contigs, n_contigs, kmax, &g);
     if (rc) return rc;

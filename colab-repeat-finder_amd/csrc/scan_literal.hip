@@ -1,0 +1,118 @@
+// scan_literal.hip -- the reference's state machine evaluated EVENT BY EVENT, for the regimes the closed form of the
+// bit-sliced kernels does not cover: min_repeats == 1, and a lock-step loop that stops early (interval mode).
+//
+// The reference walks one PerfectRepeatTracker per motif size k over the sequence (utils/perfect_repeat_tracker.py:43-61)
+// and calls output_interval_if_it_passes_filters() (:71-101) at every position i < len-k whose comparison fails, and once
+// more from done() (:67-69) at the position the tracker stopped at.  Nothing such a call does depends on an earlier call of
+// the same tracker (the run length restarts at 1, :60), and the shared (start, end) -> motif dictionary ends up, whatever
+// the order of the calls, with the SHORTEST motif among the calls that passed every test (:93-101: a longer one never
+// replaces a shorter one, a shorter or equal one always does).  So every call is an independent event:
+//
+//   one thread per (position i, motif size k); the thread leaves at once unless i is a failed comparison or the final
+//   position; it finds the run that ends at i by walking back, applies :81-101 as written -- the motif slice clamped at the
+//   end of the sequence (:82), the "N" in motif test (:83), the first filter (:86), the extension loop over seq[i+1] ==
+//   seq[i+1-k] with Python's negative-index wrap-around and its IndexError (:87-89), the second filter (:91), the
+//   primitive-motif test (:98, :108-142) -- and appends (start, end, len(motif)) to the row array.
+//
+// The host then keeps, per (start, end), the row with the shortest motif slice.  Work is one byte compare per
+// (i, k) plus O(run) per event: HBM/L2-bound byte work, nothing to tile.  It is the slow lane on purpose -- the default
+// regime (min_repeats >= 2, whole sequences) never comes here.
+#include "prf_host.h"
+
+namespace {
+
+typedef long long i64;
+
+__device__ __forceinline__ bool lit_match(const uint8_t *__restrict__ s, i64 j, i64 k) {
+    const uint8_t a = s[j];
+    return a == s[j + k] && a != 'N';  // tracker :53
+}
+
+// tracker :108-142: is the word a whole number (>= 2) of copies of a shorter unit?  The reference tries the units 1, 2, 3 and
+// then every divisor u >= 4 with 2u <= n by counting non-overlapping copies of the prefix; n/u copies in n letters tile the
+// word, so each branch is "the word has period u".
+__device__ bool lit_is_repeat(const uint8_t *__restrict__ m, i64 n) {
+    for (i64 u = 1; 2 * u <= n; u++) {
+        if (n % u) continue;
+        bool per = true;
+        for (i64 t = u; t < n; t++)
+            if (m[t] != m[t - u]) {
+                per = false;
+                break;
+            }
+        if (per) return true;
+    }
+    return false;
+}
+
+// bytes -> upper case in place (reference perfect_repeat_finder.py:33); the first byte that is not a letter is reported
+__global__ void prf_lit_upper_kernel(uint8_t *__restrict__ s, u64 n, u64 *__restrict__ bad_pos) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t c = s[i];
+        if (c >= 'a' && c <= 'z') s[i] = c = (uint8_t)(c - 32);
+        if (c < 'A' || c > 'Z') atomicMin(bad_pos, i);
+    }
+}
+
+__global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 min_repeats,
+                                                             u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
+                                                             u64 cap, u64 *__restrict__ counters) {
+    const i64 k = (i64)kmin + blockIdx.y;
+    const i64 Lk = L > k ? L - k : 0;            // tracker :50: the tracker never moves past len - k
+    const i64 pos_f = stop < Lk ? stop : Lk;     // where it stands when done() is called
+    const i64 i0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 > pos_f) return;
+    if (i0 < pos_f && lit_match(s, i0, k)) return;  // a matching position only lengthens the run (:53-56)
+
+    // the run that ends here: run_length - 1 matching positions directly in front of i0
+    i64 start = i0;
+    while (start > 0 && lit_match(s, start - 1, k)) start--;
+    i64 run = i0 - start + 1;
+
+    const i64 mlen = (start + k <= L ? start + k : L) - start;  // :82, slice clamped at the end
+    for (i64 t = 0; t < mlen; t++)
+        if (s[start + t] == 'N') return;  // :83
+
+    const i64 need = (i64)min_repeats * k;
+    i64 i = i0;
+    if (run + k - 1 >= (i64)min_span && run + k - 1 >= need) {  // :86
+        while (i < L - 1) {                                      // :87
+            i64 j = i + 1 - k;
+            if (j < 0) j += L;                                   // Python: a negative index counts from the end ...
+            if (j < 0) {                                         // ... and raises IndexError past the front
+                atomicOr(&counters[PRF_CNT_CAND], 1ull);
+                return;
+            }
+            if (s[i + 1] != s[j]) break;
+            run++;
+            i++;
+        }
+    }
+    if (run < (i64)min_span || run < need) return;               // :91
+    if (lit_is_repeat(s + start, mlen)) return;                  // :98
+    const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
+    // k of the row = length of the motif slice (< the tracker's k only where :82 clamped it): motif = seq[start : start + k]
+    if (slot < cap) rows[slot] = prf_hit_dev{(u64)start, (u64)(i + 1), (u32)mlen, contig};
+}
+
+}  // namespace
+
+hipError_t prf_launch_lit_upper(hipStream_t st, uint8_t *s, u64 n, u64 *bad_pos) {
+    if (n == 0) return hipSuccess;
+    const u64 blocks = (n + 256ull * 16 - 1) / (256ull * 16);
+    hipLaunchKernelGGL(prf_lit_upper_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, s, n, bad_pos);
+    return hipGetLastError();
+}
+
+hipError_t prf_launch_lit_events(hipStream_t st, const uint8_t *s, u64 L, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
+                                 u64 stop, u32 contig, prf_hit_dev *rows, u64 cap, u64 *counters) {
+    // threads 0 .. pos_f of the smallest k cover every k
+    const u64 Lk = L > kmin ? L - kmin : 0;
+    const u64 n_threads = (stop < Lk ? stop : Lk) + 1;
+    const u64 bx = (n_threads + 255) / 256;
+    if (bx > 0x7fffffffull || kmax - kmin + 1 > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)bx, kmax - kmin + 1), dim3(256), 0, st, s, (long long)L, kmin,
+                       min_repeats, min_span, (long long)stop, contig, rows, cap, counters);
+    return hipGetLastError();
+}

@@ -46,18 +46,21 @@ def _to_ascii(seq):
                          "the packed GPU path accepts letters only (A, C, G, T, N and, as ordinary symbols, any other letter)") from None
 
 
-def _gpu_rows(seq, fs, context=None):
-    """Closed-form rows of one sequence: list of (start, end, k), sorted by (start, end)."""
-    if fs.min_repeats < 2:
-        raise NotImplementedError(
-            "min_repeats == 1 is not supported on the GPU path: the reference's behaviour in that regime depends on "
-            "Python negative-index wrap-around (reference utils/perfect_repeat_tracker.py:87) and is not a closed form")
+def _gpu_rows(seq, fs, context=None, stop=None):
+    """Rows of one sequence: list of (start, end, k), sorted by (start, end).  min_repeats >= 2: the packed kernels (closed
+    form).  min_repeats == 1: the literal lane (csrc/scan_literal.hip), which evaluates the reference's flush call as written;
+    `stop` is then the number of lock-step iterations the reference performs (default: all of them)."""
     ctx = context or prf_native.default_context()
     try:
-        rows, _ = ctx.scan([_to_ascii(seq)], fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
+        if fs.min_repeats < 2:
+            rows, _ = ctx.scan_literal(_to_ascii(seq), fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span, stop)
+        else:
+            rows, _ = ctx.scan([_to_ascii(seq)], fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
     except prf_native.PrfError as exc:
         if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
             raise ValueError(exc.message) from None
+        if exc.code == prf_native.PRF_EINDEX:
+            raise IndexError(exc.message) from None      # reference utils/perfect_repeat_tracker.py:87
         raise
     return [(int(r["start"]), int(r["end"]), int(r["k"])) for r in rows]
 
@@ -97,12 +100,14 @@ def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress
     extension: by default a process-wide context on device PRF_DEVICE / LOCAL_RANK / 0 is used."""
     _check_settings(filter_settings)
     fs = filter_settings
-    if not hasattr(fs, "interval_start_0based") and not hasattr(fs, "interval_end"):
+    has_interval = hasattr(fs, "interval_start_0based") or hasattr(fs, "interval_end")
+    if not has_interval and fs.min_repeats >= 2:
         # no interval: N-trimming is a no-op on the rows (N never matches), SURVEY 3.4
         rows = _gpu_rows(input_sequence, fs, context)
         return [(s, e, input_sequence[s:s + k].upper()) for s, e, k in rows]
 
-    # interval mode, reference :35-46 and :61-81
+    # interval mode, reference :35-46 and :61-81.  min_repeats == 1 comes here too: its rows depend on where the sequence
+    # begins and ends (slice clamp, negative-index wrap-around), so the N-trimming of :40-46 is not a no-op there.
     seq = input_sequence.upper()
     lo = getattr(fs, "interval_start_0based", 0)
     hi = getattr(fs, "interval_end", len(seq))
@@ -113,14 +118,17 @@ def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress
         hi -= 1
         total -= 1       # the reference shortens the whole sequence by the trimmed count (:44)
     window = seq[lo:total]
-    rows = _gpu_rows(window, fs, context)
     end_position = hi - lo
     stop = _interval_cutoff(window, fs, end_position)
     if hi == len(window) and stop < len(window) - fs.min_motif_size:
-        # reference :77-78: a tracker that has not reached the end of the sequence trips the assertion
+        # reference :77-78: a tracker that has not reached the end of the sequence trips the assertion (before any done())
         raise AssertionError(f"{fs.min_motif_size}bp motif RepeatTracker did not reach end of the sequence")
-    if stop < len(window):
-        rows = [(s, e, k) for s, e, k in rows if e - k <= stop - 1]
+    if fs.min_repeats < 2:
+        rows = _gpu_rows(window, fs, context, stop=stop)       # the literal lane stops its trackers where the loop stopped
+    else:
+        rows = _gpu_rows(window, fs, context)
+        if stop < len(window):
+            rows = [(s, e, k) for s, e, k in rows if e - k <= stop - 1]
     return [(s + lo, e + lo, window[s:s + k]) for s, e, k in rows]
 
 
@@ -151,9 +159,8 @@ def _build_parser():
 def _scan_whole_fasta(fasta, bed_path, fs, report):
     """Every contig of the FASTA: one resident genome, one scan, BED written by libprf (reference :135-149 loops
     over the contigs one detect_repeats() call at a time).  report(entry, n_rows) is called per contig in order."""
-    if fs.min_repeats < 2:
-        raise NotImplementedError("min_repeats == 1 is not supported on the GPU path (see _gpu_rows)")
     try:
+        # min_repeats == 1: prf_scan serves it contig by contig on the literal lane (N-trimming included)
         prf_native.scan_fasta_to_bed(prf_native.default_context(), fasta, bed_path, fs.min_motif_size, fs.max_motif_size,
                                      fs.min_repeats, fs.min_span, on_contig=report)
     except prf_native.PrfError as exc:
@@ -190,7 +197,8 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     import torch.distributed as dist
     import multi_gpu
     if fs.min_repeats < 2:
-        raise NotImplementedError("min_repeats == 1 is not supported on the GPU path (see _gpu_rows)")
+        # the literal lane works on whole sequences (its rows depend on where a sequence begins and ends), not on tile parts
+        raise NotImplementedError("min_repeats == 1 is served on one GPU only: run without torch.distributed.run")
     backend = os.environ.get("PRF_DIST_BACKEND", "nccl")
     started_here = not dist.is_initialized()
     if backend == "nccl":

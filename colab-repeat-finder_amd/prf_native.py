@@ -18,6 +18,7 @@ PRF_EHIP = -3
 PRF_ENOMEM = -4
 PRF_EUNSUPPORTED = -5
 PRF_ESYMBOL = -6
+PRF_EINDEX = -7
 
 SCAN_DEFAULT = 0
 SCAN_FORCE_GENERIC = 1
@@ -64,7 +65,7 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
            "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split", "prf_last_hits_packed_to_device",
-           "prf_genome_contig_bases"]
+           "prf_genome_contig_bases", "prf_scan_literal"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -103,6 +104,8 @@ def load_library():
         lib.prf_scan.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_Hits),
                                  ctypes.POINTER(ScanStats)]
+        lib.prf_scan_literal.argtypes = [vp, ctypes.POINTER(_Contig), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(_Hits), ctypes.POINTER(ScanStats)]
         lib.prf_free_hits.argtypes = [ctypes.POINTER(_Hits)]
         lib.prf_free_hits.restype = None
         lib.prf_measure_hbm_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
@@ -279,6 +282,18 @@ class Context:
         stats = ScanStats()
         _check(self.lib, self.lib.prf_scan(self._h, arr, len(seqs), kmin, kmax, min_repeats, min_span, flags,
                                            ctypes.byref(hits), ctypes.byref(stats)))
+        try:
+            return _rows(hits), stats
+        finally:
+            self.lib.prf_free_hits(ctypes.byref(hits))
+
+    def scan_literal(self, seq, kmin, kmax, min_repeats, min_span, stop=None):
+        """The literal lane on one sequence (prf_scan_literal); stop: lock-step iterations performed, default all."""
+        arr, _keep = _contig_array([seq])
+        hits = _Hits()
+        stats = ScanStats()
+        _check(self.lib, self.lib.prf_scan_literal(self._h, arr, kmin, kmax, min_repeats, min_span,
+                                                   arr[0].len if stop is None else stop, ctypes.byref(hits), ctypes.byref(stats)))
         try:
             return _rows(hits), stats
         finally:

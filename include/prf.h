@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PRF_ABI_VERSION 2
+#define PRF_ABI_VERSION 3
 
 typedef enum prf_status {
     PRF_OK = 0,
@@ -41,8 +41,11 @@ typedef enum prf_status {
     PRF_ENODEV = -2,       /* no HIP device / wrong architecture                                          */
     PRF_EHIP = -3,         /* a HIP runtime call failed (see prf_last_error)                              */
     PRF_ENOMEM = -4,       /* host or device allocation failed                                            */
-    PRF_EUNSUPPORTED = -5, /* parameter regime outside the closed form (min_repeats < 2; kmax > hint)     */
-    PRF_ESYMBOL = -6       /* a byte other than ACGTN/acgtn: the packed fast path refuses it loudly        */
+    PRF_EUNSUPPORTED = -5, /* this entry point does not serve the regime (min_repeats == 1 on a packed genome; kmax > hint) */
+    PRF_ESYMBOL = -6,      /* a byte that is not a letter: refused loudly, never guessed                  */
+    PRF_EINDEX = -7        /* the reference raises IndexError on this input (utils/perfect_repeat_tracker.py:87: the
+                            * extension loop's seq[i+1-period] reaches in front of the sequence; only with min_repeats == 1
+                            * and a motif size larger than the sequence + 1)                               */
 } prf_status;
 
 typedef struct prf_ctx prf_ctx;       /* device, stream, scratch                           */
@@ -79,7 +82,7 @@ typedef struct prf_scan_stats {
     uint64_t n_candidates;  /* phase-1 candidates                                                        */
     uint64_t n_hits;        /* rows                                                                      */
     uint32_t n_launches;    /* kernel launches in the timed region                                       */
-    uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel                        */
+    uint32_t path;          /* 0 = generic kernel, 1 = vertical bit-sliced kernel, 2 = literal lane      */
     uint64_t seq;           /* fused path: serial number of this scan on its context (prf_scan_timings)  */
     uint32_t sorted_on_device; /* 1: the rows left the device sorted by (contig, start, end), no host sort   */
     uint32_t tiles_launched;   /* fused path: 65536-position tiles scanned (tiles of nothing but N are skipped)     */
@@ -138,15 +141,31 @@ int prf_genome_select(prf_genome *g, const prf_part *parts, int n_parts);
 int prf_genome_tile_classes(const prf_genome *g, uint32_t contig, uint8_t *dst, uint64_t capacity, uint64_t *n_tiles);
 
 /* The hot path on a resident genome: every k in [kmin,kmax], rows as reference :81.
- * Requires min_repeats >= 2 (PRF_EUNSUPPORTED otherwise: reference behaviour for
- * min_repeats == 1 depends on Python negative-index wrap-around). */
+ * Requires min_repeats >= 2 (PRF_EUNSUPPORTED otherwise: with min_repeats == 1 the reference's rows depend on the text in
+ * front of a run and on Python's negative-index wrap-around, which the packed planes with their guard gaps do not keep;
+ * prf_scan() and prf_scan_literal() serve that regime from the sequence bytes). */
 int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
                     uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
 
 /* One-shot convenience = prf_genome_load + prf_scan_genome + prf_genome_free.
- * This is the call that replaces the body of reference detect_repeats() (:33-81). */
+ * This is the call that replaces the body of reference detect_repeats() (:33-81).
+ * min_repeats == 1 is served by the literal lane (prf_scan_literal, contig by contig, flags ignored). */
 int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t kmin, uint32_t kmax,
              uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
+
+/* The literal lane: the reference's per-tracker flush call (utils/perfect_repeat_tracker.py:71-101) evaluated as written,
+ * one device thread per (position, motif size), on the upper-cased bytes of ONE sequence -- for the regimes outside the
+ * closed form of the packed kernels: min_repeats == 1 (:86-91 then depend on the text in front of the run, on the slice
+ * clamp at the end of the sequence and on Python's negative-index wrap-around), and a lock-step loop that stops early
+ * (interval mode, reference perfect_repeat_finder.py:66-74).  `stop` = the number of iterations that loop performs
+ * (>= contig->len: it runs to the end): every tracker stands at min(stop, len - k) when done() is called (:79).  Any
+ * min_repeats >= 1 is accepted (the rows equal prf_scan's for min_repeats >= 2 and stop >= len); work is O(len x motif
+ * sizes) byte compares, so this is the slow lane.  Rows sorted by (start, end), one row per (start, end): the shortest motif,
+ * as the reference's dictionary keeps it (:93-101); prf_hit.k = len(motif), which is smaller than the motif size only where
+ * the motif slice was clamped at the end of the sequence (:82).  PRF_EINDEX where the reference raises IndexError.  No
+ * N-trimming here (reference perfect_repeat_finder.py:40-46 is the caller's; prf_scan does it for min_repeats == 1). */
+int prf_scan_literal(prf_ctx *ctx, const prf_contig *contig, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                     uint32_t min_span, uint64_t stop, prf_hits *out, prf_scan_stats *stats);
 
 /* Pipelined scans.  prf_scan_genome_async() enqueues a scan and returns its serial number at once;
  * prf_scan_wait() collects it (row count and candidate count in *stats; kernel time through prf_scan_timings;

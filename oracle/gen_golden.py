@@ -14,6 +14,8 @@ Fixture files (all under tests/golden/):
                           (perfect_repeat_finder_tests.py:21-143), re-run here
   fuzz_small.jsonl.gz     random small cases incl. interval mode / min_repeats=1 / exceptions
   adversarial.jsonl.gz    tile/word-boundary, all-A, all-N, k > L, lowercase ...
+  min_repeats_one.jsonl.gz  min_repeats == 1 (the regime outside the closed form): random cases incl. interval mode, lower
+                          case, symbols other than ACGTN, motif sizes beyond the sequence (IndexError), N at both ends
   iupac.jsonl.gz          symbols other than ACGTN (ordinary symbols to the reference), incl. at tile edges
   synth_*.json            SURVEY 8(d) synthetic sequences (by seed/length) + reference rows
   chr22_clusters.tsv.gz   known-answer clusters mined from the reference's golden BED
@@ -150,6 +152,47 @@ def gen_fuzz_small(n_cases):
             stats[res["status"]] = stats.get(res["status"], 0) + 1
             f.write(json.dumps({"seq": seq, "settings": st, **res}) + "\n")
     print("fuzz_small:", n_cases, stats)
+
+
+def gen_min_repeats_one(n_cases):
+    """min_repeats == 1: the rows depend on the text in front of a run, on the slice clamp at the end of the sequence and
+    on negative-index wrap-around (utils/perfect_repeat_tracker.py:82-91), and N-trimming (:40-46) is not a no-op."""
+    rng = random.Random(20261004)
+    path = os.path.join(OUT, "min_repeats_one.jsonl.gz")
+    stats = {}
+    cases = []
+    fixed = [("", 1, 1, 1), ("", 1, 3, 1), ("N", 1, 2, 1), ("NNNN", 1, 5, 1), ("A", 1, 1, 1), ("A", 1, 4, 1), ("AC", 1, 6, 2),
+             ("NNACGTNN", 1, 10, 1), ("NNACGTNN", 6, 6, 1), ("ACACACAC", 1, 5, 3), ("ACACACAC", 2, 12, 1), ("acgtacgtNNacgt", 1, 8, 4),
+             ("AAAAAAAAAA", 1, 12, 1), ("ANANANANA", 1, 4, 1), ("ACGTRYACGTRY", 1, 8, 2), ("NACGTACGTACGTN", 3, 20, 5)]
+    for seq, kmin, kmax, span in fixed:
+        cases.append((seq, ns(kmin, kmax, 1, span)))
+        if seq:
+            cases.append((seq, ns(kmin, kmax, 1, span, (0, len(seq)))))
+            cases.append((seq, ns(kmin, kmax, 1, span, (len(seq) // 3, 2 * len(seq) // 3))))
+    while len(cases) < n_cases:
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "ACGTN", "ACGTacgtn", "A", "ACGTNN", "ACGTRYN", "AN"])
+        L = rng.choice([rng.randint(0, 12), rng.randint(0, 60), rng.randint(0, 300)])
+        seq = rand_seq(rng, L, alpha)
+        if rng.random() < 0.25:
+            seq = "N" * rng.randint(0, 5) + seq + "n" * rng.randint(0, 5)
+        L = len(seq)
+        kmin = rng.randint(1, 6)
+        kmax = kmin + rng.choice([0, rng.randint(0, 8), rng.randint(0, 40)])
+        if rng.random() < 0.1:
+            kmax = max(kmax, L + rng.randint(-2, 4))
+        span = rng.choice([1, 1, rng.randint(1, 12), rng.randint(1, 40)])
+        interval = None
+        if rng.random() < 0.45 and L > 0:
+            a = rng.randint(0, L)
+            b = rng.randint(a, L)
+            interval = (a, b)
+        cases.append((seq, ns(kmin, max(kmax, kmin), 1, span, interval)))
+    with gzip.open(path, "wt") as f:
+        for seq, st in cases:
+            res = run_ref(seq, st)
+            stats[res["status"]] = stats.get(res["status"], 0) + 1
+            f.write(json.dumps({"seq": seq, "settings": st, **res}) + "\n")
+    print("min_repeats_one:", len(cases), stats)
 
 
 def gen_adversarial():
@@ -350,13 +393,15 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "iupac", "clusters", "synth"]
+    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "mr1", "iupac", "clusters", "synth"]
     if "unit" in todo:
         gen_ref_unit_tests()
     if "fuzz" in todo:
         gen_fuzz_small(600 if a.quick else 4000)
     if "adv" in todo:
         gen_adversarial()
+    if "mr1" in todo:
+        gen_min_repeats_one(500 if a.quick else 3000)
     if "iupac" in todo:
         gen_iupac()
     if "clusters" in todo:

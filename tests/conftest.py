@@ -53,6 +53,11 @@ def golden_adversarial():
 
 
 @pytest.fixture(scope="session")
+def golden_min_repeats_one():
+    return load_jsonl_gz("min_repeats_one.jsonl.gz")
+
+
+@pytest.fixture(scope="session")
 def golden_iupac():
     return load_jsonl_gz("iupac.jsonl.gz")
 

@@ -11,10 +11,51 @@ from helpers import expected, outcome
 from utils.plot_utils import shift_string_by
 
 
-def closed_form_rows(seq, fs, context=None):
+def event_rows(seq, fs, stop=None):
+    """The decomposition csrc/scan_literal.hip uses, in pure Python: every flush call of a tracker (a failed comparison at
+    i < min(stop, len - k), and done() at min(stop, len - k)) is evaluated on its own as reference
+    utils/perfect_repeat_tracker.py:81-101 reads; per (start, end) the shortest motif stays.  Stands in for the literal lane
+    in these CPU tests, so that the host logic around it (N-trimming, cutoff, assertion order) is checked against the
+    reference's outputs without a GPU; the kernel itself is checked on the GPU against the same fixtures."""
+    s = seq.upper()
+    n = len(s)
+    stop = n if stop is None else min(stop, n)
+    best = {}
+    for k in range(fs.min_motif_size, fs.max_motif_size + 1):
+        nk = max(n - k, 0)
+        pos_f = min(stop, nk)
+
+        def match(j):
+            return s[j] == s[j + k] and s[j] != "N"
+        for i0 in range(pos_f + 1):
+            if i0 < pos_f and match(i0):
+                continue
+            start = i0
+            while start > 0 and match(start - 1):
+                start -= 1
+            run = i0 - start + 1
+            motif = s[start:start + k]
+            if "N" in motif:
+                continue
+            i = i0
+            if run + k - 1 >= fs.min_span and run + k - 1 >= fs.min_repeats * k:
+                while i < n - 1 and s[i + 1] == s[i + 1 - k]:      # IndexError as in the reference
+                    run += 1
+                    i += 1
+            if run < fs.min_span or run < fs.min_repeats * k:
+                continue
+            m = len(motif)
+            if any(m % d == 0 and motif == motif[:d] * (m // d) for d in range(1, m // 2 + 1)):
+                continue
+            key = (start, i + 1)
+            best[key] = min(best.get(key, m), m)
+    return sorted((a, b, m) for (a, b), m in best.items())
+
+
+def closed_form_rows(seq, fs, context=None, stop=None):
     """SURVEY 3.4 in ~15 lines; stands in for libprf in these CPU tests."""
     if fs.min_repeats < 2:
-        raise NotImplementedError
+        return event_rows(seq, fs, stop)
     s = seq.upper()
     n = len(s)
     rows = []
@@ -90,9 +131,26 @@ def test_fuzz_through_host_logic(cpu_rows, golden_fuzz):
     assert n_interval > 500
 
 
-def test_min_repeats_one_is_refused_loudly(cpu_rows):
-    with pytest.raises(NotImplementedError):
-        prf.detect_repeats("ACACACAC", argparse.Namespace(min_motif_size=1, max_motif_size=5, min_repeats=1, min_span=3))
+def test_min_repeats_one_through_host_logic(cpu_rows, golden_min_repeats_one, golden_fuzz):
+    """min_repeats == 1: N-trimming, the cutoff handed to the literal lane, assertion-before-IndexError order."""
+    statuses = set()
+    for case in golden_min_repeats_one + [c for c in golden_fuzz if c["settings"]["min_repeats"] < 2]:
+        statuses.add(case["status"])
+        assert outcome(prf.detect_repeats, case["seq"], case["settings"]) == expected(case), case
+    assert {"ok", "IndexError", "AssertionError"} <= statuses
+
+
+def test_event_decomposition_equals_closed_form_for_two_or_more_repeats(golden_fuzz):
+    """For min_repeats >= 2 and no early stop the literal lane's event model and the closed form give the same rows."""
+    n = 0
+    for case in golden_fuzz[:1500]:
+        st = case["settings"]
+        if st["min_repeats"] < 2 or case["status"] != "ok":
+            continue
+        fs = argparse.Namespace(**st)
+        assert event_rows(case["seq"], fs) == closed_form_rows(case["seq"], fs), case
+        n += 1
+    assert n > 800
 
 
 def test_find_repeats_alias():

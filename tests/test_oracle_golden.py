@@ -29,6 +29,16 @@ def test_adversarial(golden_adversarial):
         assert outcome(prf_oracle.detect_repeats, case["seq"], case["settings"]) == expected(case), case["tag"]
 
 
+def test_min_repeats_one(golden_min_repeats_one):
+    """min_repeats_one.jsonl.gz: the reference run with min_repeats == 1 (interval mode, N at the ends, k > len, IUPAC)."""
+    statuses = set()
+    assert len(golden_min_repeats_one) >= 3000
+    for case in golden_min_repeats_one:
+        statuses.add(case["status"])
+        assert outcome(prf_oracle.detect_repeats, case["seq"], case["settings"]) == expected(case), case
+    assert {"ok", "IndexError", "AssertionError"} <= statuses
+
+
 def test_symbols_other_than_acgtn_are_ordinary_symbols(golden_iupac):
     """iupac.jsonl.gz: the reference run on sequences with IUPAC letters (R == R matches, only N never does)."""
     assert len(golden_iupac) >= 270 and sum(len(c.get("rows") or []) for c in golden_iupac) > 2500
