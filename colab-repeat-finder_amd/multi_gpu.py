@@ -28,6 +28,20 @@ TILE_COST = (1.0, 1.3, 0.0, 12.0)   # ordinary tile; tile with N in reach (three
                                    # symbol outside ACGTN in reach (generic kernels: an order of magnitude slower)
 
 
+def plan_whole_contigs(lengths, world):
+    """Whole contigs dealt to `world` ranks in genome order (contiguous runs of contigs, balanced by length): the same shape
+    as plan_parts() returns, every part a whole contig.  For the literal lane (min_repeats == 1), whose rows depend on where
+    a sequence begins and ends, so a sequence cannot be cut."""
+    total = float(sum(lengths)) or 1.0
+    shares = [[] for _ in range(world)]
+    acc = 0
+    for c, n in enumerate(lengths):
+        r = min(world - 1, int((acc + n / 2.0) * world / total))
+        shares[r].append((c, 0, int(n)))
+        acc += n
+    return shares
+
+
 def plan_parts(lengths, world, tile, classes=None):
     """Cut ONE genome into `world` shares of equal cost: returns, per rank, a list of (contig, begin, end) position ranges
     cut at multiples of `tile` (prf_native.tile_positions()), in genome order -- what Genome.select() takes.  A contig

@@ -182,6 +182,12 @@ def _gpu_scan_parts(entries, settings, parts):
     return rows
 
 
+def _gpu_scan_whole_contigs(entries, settings, parts):
+    """The same for min_repeats == 1: this rank's contigs whole, through prf_scan (literal lane, N-trimming included)."""
+    rows, _stats = prf_native.default_context().scan([(e.addr, e.length) for e in entries], *settings)
+    return rows
+
+
 def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     """The same under `python -m torch.distributed.run --nproc-per-node N perfect_repeat_finder.py genome.fa`: one
     process per GPU.  The genome is cut into N shares of equal size at tile multiples (multi_gpu.plan_parts: a contig longer
@@ -196,9 +202,6 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     import torch
     import torch.distributed as dist
     import multi_gpu
-    if fs.min_repeats < 2:
-        # the literal lane works on whole sequences (its rows depend on where a sequence begins and ends), not on tile parts
-        raise NotImplementedError("min_repeats == 1 is served on one GPU only: run without torch.distributed.run")
     backend = os.environ.get("PRF_DIST_BACKEND", "nccl")
     started_here = not dist.is_initialized()
     if backend == "nccl":
@@ -211,7 +214,11 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     try:
         index, whole = prf_native.fasta_index(path)          # [(name, length)]; whole: the parsed file if there was no index
         lens = [n for _name, n in index]
-        shares = multi_gpu.plan_parts(lens, world, prf_native.tile_positions())
+        if fs.min_repeats < 2:
+            # the literal lane works on whole sequences (its rows depend on where a sequence begins and ends): whole contigs
+            shares = multi_gpu.plan_whole_contigs(lens, world)
+        else:
+            shares = multi_gpu.plan_parts(lens, world, prf_native.tile_positions())
         mine = shares[rank]
         needed = sorted({c for c, _b, _e in mine})
         counts = np.zeros(len(index), dtype=np.int64)
@@ -224,7 +231,8 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
                 entries = [r[0] for r in readers]
             local = {c: i for i, c in enumerate(needed)}
             settings = (fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
-            rows = (scan_fn or _gpu_scan_parts)(entries, settings, [(local[c], b, e) for c, b, e in mine]) if mine else []
+            scan = scan_fn or (_gpu_scan_whole_contigs if fs.min_repeats < 2 else _gpu_scan_parts)
+            rows = scan(entries, settings, [(local[c], b, e) for c, b, e in mine]) if mine else []
             rows = np.asarray(rows, dtype=multi_gpu.ROW_DTYPE)
             per_local = prf_native.write_bed(part_path, entries, rows)                  # motif text from this rank's own contigs
             for c, n_rows in zip(needed, per_local):

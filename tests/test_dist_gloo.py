@@ -132,7 +132,7 @@ def test_a_failure_on_one_rank_is_raised_on_every_rank():
     mp.spawn(_failing_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
-def _cli_worker(rank, world, port, workdir, fasta_path, out_prefix):
+def _cli_worker(rank, world, port, workdir, fasta_path, out_prefix, extra=()):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -152,7 +152,13 @@ def _cli_worker(rank, world, port, workdir, fasta_path, out_prefix):
                     rows.append((a, b, k, ci))
         return rows
     prf._gpu_scan_parts = oracle_parts
-    prf.main(["-min", "1", "-max", "20", "-o", out_prefix, fasta_path])
+
+    def oracle_whole(entries, settings, parts):   # stands in for prf_scan on this rank's whole contigs (min_repeats == 1)
+        assert all(b == 0 and en == entries[c].length for c, b, en in parts)
+        return [(a, b, ml, ci) for ci, e in enumerate(entries)
+                for a, b, ml, _k in prf_oracle.detect_rows(ctypes.string_at(e.addr, e.length), *settings)]
+    prf._gpu_scan_whole_contigs = oracle_whole
+    prf.main(["-min", "1", "-max", "20", "-o", out_prefix, fasta_path] + list(extra))
 
 
 def test_command_line_under_two_ranks_writes_the_whole_genome_bed(tmp_path, capfd):
@@ -186,3 +192,10 @@ def test_command_line_under_two_ranks_writes_the_whole_genome_bed(tmp_path, capf
     mp.spawn(_cli_worker, args=(2, _free_port(), str(tmp_path), str(fasta), "indexed"), nprocs=2, join=True)
     assert open(tmp_path / "indexed.bed").read() == want
     assert not [p for p in os.listdir(tmp_path) if ".part" in p]
+    # min_repeats == 1 (the literal lane): whole contigs dealt to the ranks in genome order
+    fs1 = argparse.Namespace(min_motif_size=1, max_motif_size=20, min_repeats=1, min_span=12)
+    want1 = "".join(f"{name}\t{s}\t{e}\t{m}\n" for name, seq in contigs.items() for s, e, m in prf_oracle.detect_repeats(seq, fs1))
+    assert want1.count("\n") > 300 and want1 != want
+    mp.spawn(_cli_worker, args=(2, _free_port(), str(tmp_path), str(fasta), "one", ("--min-repeats", "1", "--min-span", "12")),
+             nprocs=2, join=True)
+    assert open(tmp_path / "one.bed").read() == want1

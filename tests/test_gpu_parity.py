@@ -815,6 +815,17 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
                           "toy.fasta"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert open("two_ranks.bed").read() == want and res.stdout.count("Wrote results to two_ranks.bed") == 1
+    # min_repeats == 1 (the literal lane): whole FASTA in one process, and the same under two ranks (whole contigs per rank)
+    fs1 = argparse.Namespace(min_motif_size=1, max_motif_size=12, min_repeats=1, min_span=10)
+    want1 = "".join(f"{name}\t{s}\t{e}\t{m}\n" for name, seq in contigs.items() for s, e, m in prf_oracle.detect_repeats(seq, fs1))
+    prf.main(["-max", "12", "--min-repeats", "1", "--min-span", "10", "-o", "one", "toy.fasta"])
+    assert open("one.bed").read() == want1 and want1.count("\n") > 100 and want1 != want
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29534", os.path.join(PKG, "perfect_repeat_finder.py"), "-max", "12",
+                          "--min-repeats", "1", "--min-span", "10", "-o", "one_two_ranks", "toy.fasta"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert open("one_two_ranks.bed").read() == want1
     prf.main(["-min", "2", "-max", "6", "CACACACACACAGGGTTTTTTTTTTT"])
     assert open("repeats.tsv").read() == "start_0based\tend\tmotif\n0\t12\tCA\n"
     assert "Found 1 repeats" in capsys.readouterr().out
