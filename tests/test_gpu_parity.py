@@ -91,7 +91,7 @@ def test_literal_lane_vs_oracle_and_vs_packed_kernels(ctx):
         a = [(int(x["start"]), int(x["end"]), int(x["k"])) for x in lit]
         assert a == [(int(x["start"]), int(x["end"]), int(x["k"])) for x in fused]
         assert a == oracle_rows(seq, kmin, kmax, r, span)
-        assert len(a) > 300
+        assert len(a) >= 20
     contigs = [b"NNNN" + seq[3_000:9_000] + b"nn", b"", b"NNN", seq[70_000:70_500], b"ACGTRYACGTRYACGTRYnn", contig_like[:12_000]]
     rows, stats = ctx.scan(contigs, 1, 8, 1, 5)
     got = {}
