@@ -310,9 +310,23 @@ def test_errors_cross_the_boundary_cleanly(ctx):
     assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
     rows, _ = ctx.scan([b"ACGTRYACGT"], 1, 5, 3, 9)          # IUPAC letters are ordinary symbols (see the test below)
     assert len(rows) == 0
+    g = ctx.load([b"ACGT"], 5)
+    try:
+        with pytest.raises(prf_native.PrfError) as info:     # min_repeats == 1 needs the sequence bytes (literal lane), not packed planes
+            g.scan(1, 5, 1, 9)
+        assert info.value.code == prf_native.PRF_EUNSUPPORTED
+    finally:
+        g.free()
+    rows, stats = ctx.scan([b"ACGT"], 1, 5, 1, 9)            # prf_scan serves it on the literal lane
+    assert len(rows) == 0 and stats.path == 2
+    rows, _ = ctx.scan([b"NNACGTACGTAC"], 1, 5, 1, 9)
+    assert rows_as_tuples(rows) == [(0, 2, 12, 4)]
+    with pytest.raises(prf_native.PrfError) as info:         # the reference's IndexError (tracker :87): motif size > len + 1
+        ctx.scan_literal(b"ACG", 1, 9, 1, 1)
+    assert info.value.code == prf_native.PRF_EINDEX
     with pytest.raises(prf_native.PrfError) as info:
-        ctx.scan([b"ACGT"], 1, 5, 1, 9)
-    assert info.value.code == prf_native.PRF_EUNSUPPORTED
+        ctx.scan_literal(b"ACGT-ACGT", 1, 5, 1, 1)
+    assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
     with pytest.raises(prf_native.PrfError) as info:
         ctx.scan([b"ACGT"], 0, 5, 3, 9)
     assert info.value.code == prf_native.PRF_EINVAL

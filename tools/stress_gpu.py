@@ -56,5 +56,25 @@ while time.time() < t_end:
                   'got', len(got), 'want', len(want), 'first diff', next((x for x in zip(got, want) if x[0] != x[1]), None))
             if bad > 5: sys.exit(1)
     g.free()
+    # the literal lane (min_repeats == 1) on the same contigs through prf_scan: N-trimming, slice clamp, wrap-around, IndexError
+    small = [c[:rng.choice([0, 1, 7, 300, 20000, 90000])] for c in contigs]
+    kmin = rng.randint(1, 6)
+    kmax = kmin + rng.choice([0, 3, 10, 40])
+    span = rng.choice([1, 5, 9, 12, 30])
+    try:
+        want = [(ci, a, b, ml) for ci, s in enumerate(small) for a, b, ml, _k in prf_oracle.detect_rows(s, kmin, kmax, 1, span)]
+    except IndexError:
+        want = 'IndexError'
+    try:
+        rows, st = ctx.scan(small, kmin, kmax, 1, span)
+        got = [(int(x['contig']), int(x['start']), int(x['end']), int(x['k'])) for x in rows]
+    except prf_native.PrfError as exc:
+        got = 'IndexError' if exc.code == prf_native.PRF_EINDEX else repr(exc)
+    cases += 1
+    if got != want:
+        bad += 1
+        print('MISMATCH (literal lane)', dict(kmin=kmin, kmax=kmax, span=span, lens=[len(c) for c in small]),
+              'got', got if isinstance(got, str) else len(got), 'want', want if isinstance(want, str) else len(want))
+        if bad > 5: sys.exit(1)
 print(f'stress: {cases} scans, {bad} mismatches')
 sys.exit(1 if bad else 0)
