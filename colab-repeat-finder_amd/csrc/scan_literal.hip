@@ -8,8 +8,9 @@
 // the order of the calls, with the SHORTEST motif among the calls that passed every test (:93-101: a longer one never
 // replaces a shorter one, a shorter or equal one always does).  So every call is an independent event:
 //
-//   one thread per (position i, motif size k); the thread leaves at once unless i is a failed comparison or the final
-//   position; it finds the run that ends at i by walking back, applies :81-101 as written -- the motif slice clamped at the
+//   one thread per (four positions, motif size k); a position is left at once unless it is a failed comparison or the final
+//   position; it finds the run that ends at i by walking back, applies :81-101 as written (the N test moved behind the
+//   filters, see there) -- the motif slice clamped at the
 //   end of the sequence (:82), the "N" in motif test (:83), the first filter (:86), the extension loop over seq[i+1] ==
 //   seq[i+1-k] with Python's negative-index wrap-around and its IndexError (:87-89), the second filter (:91), the
 //   primitive-motif test (:98, :108-142) -- and appends (start, end, len(motif)) to the row array.
@@ -55,45 +56,72 @@ __global__ void prf_lit_upper_kernel(uint8_t *__restrict__ s, u64 n, u64 *__rest
     }
 }
 
-__global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 min_repeats,
-                                                             u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
-                                                             u64 cap, u64 *__restrict__ counters) {
-    const i64 k = (i64)kmin + blockIdx.y;
-    const i64 Lk = L > k ? L - k : 0;            // tracker :50: the tracker never moves past len - k
-    const i64 pos_f = stop < Lk ? stop : Lk;     // where it stands when done() is called
-    const i64 i0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i0 > pos_f) return;
-    if (i0 < pos_f && lit_match(s, i0, k)) return;  // a matching position only lengthens the run (:53-56)
-
+// one flush call of tracker k at position i0 (a failed comparison, or the position done() finds the tracker at)
+__device__ void lit_event(const uint8_t *__restrict__ s, i64 L, i64 k, i64 i0, u32 min_repeats, u32 min_span, u32 contig,
+                          prf_hit_dev *__restrict__ rows, u64 cap, u64 *__restrict__ counters) {
     // the run that ends here: run_length - 1 matching positions directly in front of i0
     i64 start = i0;
     while (start > 0 && lit_match(s, start - 1, k)) start--;
     i64 run = i0 - start + 1;
 
     const i64 mlen = (start + k <= L ? start + k : L) - start;  // :82, slice clamped at the end
-    for (i64 t = 0; t < mlen; t++)
-        if (s[start + t] == 'N') return;  // :83
-
+    // :83 ("N" in motif -> return) reads up to k bytes and nearly every event fails a filter anyway, so it is evaluated
+    // LAST: nothing between :83 and :98 has a side effect except the IndexError of :87, which is therefore raised only after
+    // the N test has been made at that point.
     const i64 need = (i64)min_repeats * k;
     i64 i = i0;
+    bool index_error = false;
     if (run + k - 1 >= (i64)min_span && run + k - 1 >= need) {  // :86
         while (i < L - 1) {                                      // :87
             i64 j = i + 1 - k;
             if (j < 0) j += L;                                   // Python: a negative index counts from the end ...
             if (j < 0) {                                         // ... and raises IndexError past the front
-                atomicOr(&counters[PRF_CNT_CAND], 1ull);
-                return;
+                index_error = true;
+                break;
             }
             if (s[i + 1] != s[j]) break;
             run++;
             i++;
         }
     }
-    if (run < (i64)min_span || run < need) return;               // :91
+    if (!index_error && (run < (i64)min_span || run < need)) return;  // :91
+    for (i64 t = 0; t < mlen; t++)
+        if (s[start + t] == 'N') return;  // :83
+    if (index_error) {
+        atomicOr(&counters[PRF_CNT_CAND], 1ull);
+        return;
+    }
     if (lit_is_repeat(s + start, mlen)) return;                  // :98
     const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
     // k of the row = length of the motif slice (< the tracker's k only where :82 clamped it): motif = seq[start : start + k]
     if (slot < cap) rows[slot] = prf_hit_dev{(u64)start, (u64)(i + 1), (u32)mlen, contig};
+}
+
+// Four positions per thread: one aligned dword of the sequence against the (unaligned) dword k bytes further on, taken from
+// two aligned dwords with v_alignbyte_b32.  The buffer has 16 readable bytes behind the sequence.
+__global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 min_repeats,
+                                                             u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
+                                                             u64 cap, u64 *__restrict__ counters) {
+    const i64 k = (i64)kmin + blockIdx.y;
+    const i64 Lk = L > k ? L - k : 0;            // tracker :50: the tracker never moves past len - k
+    const i64 pos_f = stop < Lk ? stop : Lk;     // where it stands when done() is called
+    const i64 i_base = 4 * ((i64)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i_base > pos_f) return;
+    u32 a = 0, b = 0;
+    if (i_base < pos_f) {                        // then i_base + k < L: both dwords lie inside the buffer
+        a = *(const u32 *)(s + i_base);
+        const u64 q = (u64)(i_base + k);
+        const u32 *w = (const u32 *)(s + (q & ~3ull));
+        b = __builtin_amdgcn_alignbyte(w[1], w[0], (u32)(q & 3ull));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const i64 i0 = i_base + t;
+        if (i0 > pos_f) break;
+        const u32 ca = (a >> (8 * t)) & 0xffu, cb = (b >> (8 * t)) & 0xffu;
+        if (i0 < pos_f && ca == cb && ca != 'N') continue;  // a matching position only lengthens the run (:53-56)
+        lit_event(s, L, k, i0, min_repeats, min_span, contig, rows, cap, counters);
+    }
 }
 
 }  // namespace
@@ -107,9 +135,9 @@ hipError_t prf_launch_lit_upper(hipStream_t st, uint8_t *s, u64 n, u64 *bad_pos)
 
 hipError_t prf_launch_lit_events(hipStream_t st, const uint8_t *s, u64 L, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
                                  u64 stop, u32 contig, prf_hit_dev *rows, u64 cap, u64 *counters) {
-    // threads 0 .. pos_f of the smallest k cover every k
+    // positions 0 .. pos_f of the smallest k cover every k
     const u64 Lk = L > kmin ? L - kmin : 0;
-    const u64 n_threads = (stop < Lk ? stop : Lk) + 1;
+    const u64 n_threads = (stop < Lk ? stop : Lk) / 4 + 1;  // four positions per thread
     const u64 bx = (n_threads + 255) / 256;
     if (bx > 0x7fffffffull || kmax - kmin + 1 > 65535u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)bx, kmax - kmin + 1), dim3(256), 0, st, s, (long long)L, kmin,
