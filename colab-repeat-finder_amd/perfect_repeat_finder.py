@@ -126,7 +126,12 @@ def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress
     if fs.min_repeats < 2:
         rows = _gpu_rows(window, fs, context, stop=stop)       # the literal lane stops its trackers where the loop stopped
     else:
-        rows = _gpu_rows(window, fs, context)
+        # The rows the reference has written when its loop stops after `stop` iterations are the runs whose failed comparison
+        # lies below `stop`; such a run ends at most max_motif_size bases later, so only that much of the sequence is scanned
+        # (an interval at the front of a chromosome does not pay for the rest of it).  Runs cut off by the shortened end
+        # have their failed comparison at or behind `stop` and are dropped with the others.
+        scanned = window if stop >= len(window) else window[:stop + fs.max_motif_size + 1]
+        rows = _gpu_rows(scanned, fs, context)
         if stop < len(window):
             rows = [(s, e, k) for s, e, k in rows if e - k <= stop - 1]
     return [(s + lo, e + lo, window[s:s + k]) for s, e, k in rows]
