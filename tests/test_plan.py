@@ -57,3 +57,20 @@ def test_parameter_sweep():
         check(kmin, kmin + width, r, span)
     check(1, 480, 3, 9)
     check(300, 481, 2, 5)
+
+
+def test_whole_contig_shares_cover_the_genome_in_order():
+    """multi_gpu.plan_whole_contigs (min_repeats == 1 under N ranks): every contig exactly once, whole, ranks in genome order
+    (so the ranks' BED pieces concatenate), lengths balanced as far as whole contigs allow."""
+    import multi_gpu
+    hg38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+            135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+            50818468, 156040895, 57227415, 16569]
+    for lens in (hg38, [5], [0, 0, 7, 0], [], [10] * 3):
+        for world in (1, 2, 3, 8):
+            shares = multi_gpu.plan_whole_contigs(lens, world)
+            assert len(shares) == world
+            flat = [p for share in shares for p in share]
+            assert flat == [(c, 0, n) for c, n in enumerate(lens)]          # whole contigs, genome order across the ranks
+    loads = [sum(e for _c, _b, e in share) for share in multi_gpu.plan_whole_contigs(hg38, 8)]
+    assert max(loads) < 1.5 * sum(hg38) / 8
