@@ -99,13 +99,16 @@ __device__ void lit_event(const uint8_t *__restrict__ s, i64 L, i64 k, i64 i0, u
 
 // Four positions per thread: one aligned dword of the sequence against the (unaligned) dword k bytes further on, taken from
 // two aligned dwords with v_alignbyte_b32.  The buffer has 16 readable bytes behind the sequence.
-__global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 min_repeats,
+__global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 n_k, u32 min_repeats,
                                                              u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
                                                              u64 cap, u64 *__restrict__ counters) {
-    const i64 k = (i64)kmin + blockIdx.y;
+    // the motif size is the fast index of the grid: the workgroups resident at one time read the same stretch of the
+    // sequence for all motif sizes, which L2 then serves (with the motif size as the slow index every size streamed the
+    // whole sequence from HBM again: FETCH_SIZE 1.5 GB per launch for 50 MB x 50 sizes)
+    const i64 k = (i64)kmin + blockIdx.x % n_k;
     const i64 Lk = L > k ? L - k : 0;            // tracker :50: the tracker never moves past len - k
     const i64 pos_f = stop < Lk ? stop : Lk;     // where it stands when done() is called
-    const i64 i_base = 4 * ((i64)blockIdx.x * blockDim.x + threadIdx.x);
+    const i64 i_base = 4 * ((i64)(blockIdx.x / n_k) * blockDim.x + threadIdx.x);
     if (i_base > pos_f) return;
     u32 a = 0, b = 0;
     if (i_base < pos_f) {                        // then i_base + k < L: both dwords lie inside the buffer
@@ -139,8 +142,9 @@ hipError_t prf_launch_lit_events(hipStream_t st, const uint8_t *s, u64 L, u32 km
     const u64 Lk = L > kmin ? L - kmin : 0;
     const u64 n_threads = (stop < Lk ? stop : Lk) / 4 + 1;  // four positions per thread
     const u64 bx = (n_threads + 255) / 256;
-    if (bx > 0x7fffffffull || kmax - kmin + 1 > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)bx, kmax - kmin + 1), dim3(256), 0, st, s, (long long)L, kmin,
+    const u64 n_k = kmax - kmin + 1;
+    if (bx * n_k > 0x7fffffffull) return hipErrorInvalidValue;  // one-dimensional grid: workgroup b = (positions b / n_k, size b % n_k)
+    hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)(bx * n_k)), dim3(256), 0, st, s, (long long)L, kmin, (u32)n_k,
                        min_repeats, min_span, (long long)stop, contig, rows, cap, counters);
     return hipGetLastError();
 }
