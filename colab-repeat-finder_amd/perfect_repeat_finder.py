@@ -24,6 +24,9 @@ if _HERE not in sys.path:
 import prf_native  # noqa: E402
 
 
+_LEADING_N = re.compile("N*")
+
+
 def _check_settings(fs):
     """Same checks, same messages, same AttributeError-on-missing behaviour as reference :23-30."""
     checks = (
@@ -72,6 +75,7 @@ def _interval_cutoff(seq, fs, end_position):
     control logic over a handful of positions; the scan itself stays on the GPU."""
     n = len(seq)
     ks = range(fs.min_motif_size, fs.max_motif_size + 1)
+    end_position = max(end_position, -1)   # an interval that ends in front of its start: the loop may stop at position 0
 
     def matches(j, k):
         return seq[j] == seq[j + k] and seq[j] != "N"
@@ -112,11 +116,18 @@ def detect_repeats(input_sequence, filter_settings, verbose=False, show_progress
     lo = getattr(fs, "interval_start_0based", 0)
     hi = getattr(fs, "interval_end", len(seq))
     total = len(seq)
-    while lo < hi and seq[lo] == "N":
-        lo += 1
-    while hi > lo and seq[hi - 1] == "N":
-        hi -= 1
-        total -= 1       # the reference shortens the whole sequence by the trimmed count (:44)
+    if 0 <= lo <= hi <= total:
+        # the two loops of reference :40-44 without a Python iteration per base (chr22 begins with 10.5 M of N)
+        lo = _LEADING_N.match(seq, lo, hi).end()
+        dropped = (hi - lo) - len(seq[lo:hi].rstrip("N"))
+        hi -= dropped
+        total -= dropped  # the reference shortens the whole sequence by the trimmed count (:44)
+    else:                # out-of-range interval: the loops as the reference has them (negative indices wrap, IndexError)
+        while lo < hi and seq[lo] == "N":
+            lo += 1
+        while hi > lo and seq[hi - 1] == "N":
+            hi -= 1
+            total -= 1
     window = seq[lo:total]
     end_position = hi - lo
     stop = _interval_cutoff(window, fs, end_position)

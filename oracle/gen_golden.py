@@ -16,6 +16,7 @@ Fixture files (all under tests/golden/):
   adversarial.jsonl.gz    tile/word-boundary, all-A, all-N, k > L, lowercase ...
   min_repeats_one.jsonl.gz  min_repeats == 1 (the regime outside the closed form): random cases incl. interval mode, lower
                           case, symbols other than ACGTN, motif sizes beyond the sequence (IndexError), N at both ends
+  odd_intervals.jsonl.gz  interval bounds reversed / outside the sequence / on N, min_repeats 1-3
   iupac.jsonl.gz          symbols other than ACGTN (ordinary symbols to the reference), incl. at tile edges
   synth_*.json            SURVEY 8(d) synthetic sequences (by seed/length) + reference rows
   chr22_clusters.tsv.gz   known-answer clusters mined from the reference's golden BED
@@ -193,6 +194,27 @@ def gen_min_repeats_one(n_cases):
             stats[res["status"]] = stats.get(res["status"], 0) + 1
             f.write(json.dumps({"seq": seq, "settings": st, **res}) + "\n")
     print("min_repeats_one:", len(cases), stats)
+
+
+def gen_odd_intervals(n_cases):
+    """Intervals the command line never produces but detect_repeats() accepts: end in front of start, bounds outside the
+    sequence (negative indices wrap, IndexError past the ends), N at the interval edges; min_repeats 1-3."""
+    rng = random.Random(20261005)
+    path = os.path.join(OUT, "odd_intervals.jsonl.gz")
+    stats = {}
+    with gzip.open(path, "wt") as f:
+        for it in range(n_cases):
+            L = rng.randint(0, 200)
+            body = "".join(rng.choice("ACGTNn" if rng.random() < 0.5 else "ACac") for _ in range(L))
+            seq = "N" * rng.randint(0, 6) + body + "N" * rng.randint(0, 6)
+            L = len(seq)
+            kmin = rng.randint(1, 4)
+            st = ns(kmin, kmin + rng.randint(0, 12), rng.randint(1, 3), rng.randint(1, 12),
+                    (rng.randint(-3, L + 3), rng.randint(-3, L + 3)))
+            res = run_ref(seq, st)
+            stats[res["status"]] = stats.get(res["status"], 0) + 1
+            f.write(json.dumps({"seq": seq, "settings": st, **res}) + "\n")
+    print("odd_intervals:", n_cases, stats)
 
 
 def gen_adversarial():
@@ -393,13 +415,15 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "mr1", "iupac", "clusters", "synth"]
+    todo = a.only.split(",") if a.only else ["unit", "fuzz", "adv", "odd", "mr1", "iupac", "clusters", "synth"]
     if "unit" in todo:
         gen_ref_unit_tests()
     if "fuzz" in todo:
         gen_fuzz_small(600 if a.quick else 4000)
     if "adv" in todo:
         gen_adversarial()
+    if "odd" in todo:
+        gen_odd_intervals(300 if a.quick else 1500)
     if "mr1" in todo:
         gen_min_repeats_one(500 if a.quick else 3000)
     if "iupac" in todo:

@@ -58,6 +58,11 @@ def golden_min_repeats_one():
 
 
 @pytest.fixture(scope="session")
+def golden_odd_intervals():
+    return load_jsonl_gz("odd_intervals.jsonl.gz")
+
+
+@pytest.fixture(scope="session")
 def golden_iupac():
     return load_jsonl_gz("iupac.jsonl.gz")
 

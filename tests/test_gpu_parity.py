@@ -68,6 +68,12 @@ def test_min_repeats_one(detect, golden_min_repeats_one):
     assert {"ok", "IndexError", "AssertionError"} <= statuses
 
 
+def test_odd_intervals(detect, golden_odd_intervals):
+    """Interval bounds reversed, outside the sequence or on N, min_repeats 1-3: 1500 reference-generated cases."""
+    for case in golden_odd_intervals:
+        assert outcome(detect, case["seq"], case["settings"]) == expected(case), case
+
+
 def test_literal_lane_vs_oracle_and_vs_packed_kernels(ctx):
     """Seeded inputs at sizes the oracle finishes in seconds: (a) min_repeats == 1 against the oracle, incl. a long
     homopolymer and N blocks; (b) for min_repeats >= 2 the literal lane, the fused kernel and the oracle agree row for row;

@@ -140,6 +140,15 @@ def test_min_repeats_one_through_host_logic(cpu_rows, golden_min_repeats_one, go
     assert {"ok", "IndexError", "AssertionError"} <= statuses
 
 
+def test_odd_intervals_through_host_logic(cpu_rows, golden_odd_intervals):
+    """Interval bounds reversed / outside the sequence / on N: trimming fast path vs the reference's loops, cutoff, assertion."""
+    statuses = set()
+    for case in golden_odd_intervals:
+        statuses.add(case["status"])
+        assert outcome(prf.detect_repeats, case["seq"], case["settings"]) == expected(case), case
+    assert {"ok", "IndexError"} <= statuses
+
+
 def test_event_decomposition_equals_closed_form_for_two_or_more_repeats(golden_fuzz):
     """For min_repeats >= 2 and no early stop the literal lane's event model and the closed form give the same rows."""
     n = 0

@@ -39,6 +39,13 @@ def test_min_repeats_one(golden_min_repeats_one):
     assert {"ok", "IndexError", "AssertionError"} <= statuses
 
 
+def test_odd_intervals(golden_odd_intervals):
+    """odd_intervals.jsonl.gz: interval bounds reversed, outside the sequence, on N (reference perfect_repeat_finder.py:35-46)."""
+    assert len(golden_odd_intervals) >= 1500
+    for case in golden_odd_intervals:
+        assert outcome(prf_oracle.detect_repeats, case["seq"], case["settings"]) == expected(case), case
+
+
 def test_symbols_other_than_acgtn_are_ordinary_symbols(golden_iupac):
     """iupac.jsonl.gz: the reference run on sequences with IUPAC letters (R == R matches, only N never does)."""
     assert len(golden_iupac) >= 270 and sum(len(c.get("rows") or []) for c in golden_iupac) > 2500
