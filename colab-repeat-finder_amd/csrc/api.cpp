@@ -569,6 +569,9 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     return PRF_OK;
 }
 
+static int literal_genome(prf_ctx *c, const prf_genome *g, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_hits *out,
+                          prf_scan_stats *stats);
+
 static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
                      uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats) {
     if (!c || !g) return fail(PRF_EINVAL, "prf_scan_genome: NULL context or genome");
@@ -579,9 +582,11 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     if (kmax < kmin) return fail(PRF_EINVAL, "max_motif_size is set to %u. It must be at least min_motif_size.", kmax);
     if (min_repeats < 1) return fail(PRF_EINVAL, "min_repeats is set to %u. It must be at least 1.", min_repeats);
     if (min_span < 1) return fail(PRF_EINVAL, "min_span is set to %u. It must be at least 1.", min_span);
-    if (min_repeats < 2)
-        return fail(PRF_EUNSUPPORTED, "min_repeats == 1 is outside the closed form of the packed kernels: use prf_scan() or "
-                                      "prf_scan_literal() on the sequence bytes (scan_literal.hip)");
+    if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
+    if (min_repeats < 2) {  // outside the closed form of the packed kernels: the literal lane on the bytes rebuilt from the planes
+        HIPCHK(hipSetDevice(c->dev));
+        return literal_genome(c, g, kmin, kmax, min_repeats, min_span, out, stats);
+    }
     if (kmax > g->kmax_hint)
         return fail(PRF_EUNSUPPORTED, "max_motif_size %u exceeds the kmax_hint %u this genome was packed with", kmax,
                     g->kmax_hint);
@@ -836,15 +841,12 @@ struct dev_free {
 };
 }  // namespace
 
-static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
-                       u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
-    const u64 L = ct.len;
-    if (L && !ct.ascii) return fail(PRF_EINVAL, "prf_scan_literal: NULL sequence");
-    if (L >= (1ull << 40)) return fail(PRF_EUNSUPPORTED, "prf_scan_literal: input too large (2^40 positions)");
+// d_seq: L bytes on the device (4-byte aligned, 16 readable bytes behind them); upper: not upper-cased / validated yet
+static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats,
+                          u32 min_span, u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
     if (stop > L) stop = L;
-    dev_free seq, rows;
-    HIPCHK(hipMalloc(&seq.p, L + 16));
-    if (L) HIPCHK(hipMemcpyAsync(seq.p, ct.ascii, L, hipMemcpyHostToDevice, c->stream));
+    dev_free rows;
+    struct { uint8_t *p; } seq{d_seq};
     u64 cap = L / 16 + 4096;
     u64 *h = c->h_counters;
     for (int attempt = 0;; attempt++) {
@@ -852,7 +854,7 @@ static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 k
         HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
         HIPCHK(hipMemsetAsync(c->d_counters + PRF_CNT_BADPOS, 0xFF, sizeof(u64), c->stream));
         HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        if (attempt == 0) HIPCHK(prf_launch_lit_upper(c->stream, (uint8_t *)seq.p, L, c->d_counters + PRF_CNT_BADPOS));
+        if (attempt == 0 && upper) HIPCHK(prf_launch_lit_upper(c->stream, (uint8_t *)seq.p, L, c->d_counters + PRF_CNT_BADPOS));
         HIPCHK(prf_launch_lit_events(c->stream, (const uint8_t *)seq.p, L, kmin, kmax, min_repeats, min_span, stop, contig_index,
                                      (prf_hit_dev *)rows.p, cap, c->d_counters));
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -861,7 +863,7 @@ static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 k
         float t = 0;
         HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
         *ms += t;
-        *launches += attempt == 0 ? 2 : 1;
+        *launches += attempt == 0 && upper ? 2 : 1;
         if (h[PRF_CNT_BADPOS] != ~0ull)
             return fail(PRF_ESYMBOL,
                         "unsupported symbol at contig %u position %llu: only letters are accepted (A, C, G, T, N and -- as ordinary "
@@ -895,6 +897,82 @@ static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 k
     }
 }
 
+static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
+                       u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
+    const u64 L = ct.len;
+    if (L && !ct.ascii) return fail(PRF_EINVAL, "prf_scan_literal: NULL sequence");
+    if (L >= (1ull << 40)) return fail(PRF_EUNSUPPORTED, "prf_scan_literal: input too large (2^40 positions)");
+    dev_free seq;
+    HIPCHK(hipMalloc(&seq.p, L + 16));
+    if (L) HIPCHK(hipMemcpyAsync(seq.p, ct.ascii, L, hipMemcpyHostToDevice, c->stream));
+    return literal_device(c, (uint8_t *)seq.p, L, true, contig_index, kmin, kmax, min_repeats, min_span, stop, rows_out, ms, launches);
+}
+
+static int literal_finish(prf_ctx *c, std::vector<prf_hit> &rows, float ms, u32 launches, u64 positions, prf_hits *out,
+                          prf_scan_stats *stats) {
+    c->last_nhits = 0;  // the rows of this lane live on the host only
+    c->last_rows = nullptr;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->scan_ms = stats->phase1_ms = ms;
+        stats->positions = positions;
+        stats->packed_bytes = positions;  // this lane reads the bytes themselves
+        stats->n_candidates = stats->n_hits = rows.size();
+        stats->n_launches = launches;
+        stats->path = 2;
+    }
+    if (!out || rows.empty()) return PRF_OK;
+    prf_hit *r = (prf_hit *)malloc(rows.size() * sizeof(prf_hit));
+    if (!r) return fail(PRF_ENOMEM, "prf_scan_literal: cannot allocate %zu rows", rows.size());
+    memcpy(r, rows.data(), rows.size() * sizeof(prf_hit));
+    out->rows = r;
+    out->n = rows.size();
+    return PRF_OK;
+}
+
+// min_repeats == 1 on a RESIDENT genome: the upper-cased bytes of every contig are rebuilt on the device from the linear
+// planes (H, L, X and the code planes of the symbols outside ACGTN), trimmed of the N at both ends (reference
+// perfect_repeat_finder.py:40-46) and handed to the literal lane -- nothing crosses PCIe but the rows.
+static int literal_genome(prf_ctx *c, const prf_genome *g, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_hits *out,
+                          prf_scan_stats *stats) {
+    if (g->sel_on)
+        return fail(PRF_EUNSUPPORTED, "min_repeats == 1 scans whole contigs (its rows depend on where a sequence begins and ends): "
+                                      "clear the selection of parts (prf_genome_select with n_parts == 0)");
+    if (c->sink) return fail(PRF_EUNSUPPORTED, "min_repeats == 1: not with a row sink (the rows of the literal lane are deduplicated on the host)");
+    if (c->slot[0].seq || c->slot[1].seq) return fail(PRF_EINVAL, "prf_scan_genome: pipelined scans are in flight on this context");
+    std::vector<prf_hit> rows;
+    float ms = 0;
+    u32 launches = 0;
+    for (size_t ci = 0; ci < g->len.size(); ci++) {
+        const u64 len = g->len[ci];
+        u64 lo = len, hi = len;  // nothing but N (or empty): the reference's window is seq[len:len]
+        if (len) {
+            u64 fl[2] = {~0ull, 0ull};
+            HIPCHK(hipMemcpyAsync(c->d_counters, fl, sizeof fl, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(prf_launch_lit_trim(c->stream, g->X, g->E, g->base[ci] >> 6, len, c->d_counters));
+            HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            launches++;
+            if (c->h_counters[0] != ~0ull) { lo = c->h_counters[0]; hi = c->h_counters[1]; }
+        }
+        const u64 n = hi - lo;
+        dev_free seq;
+        HIPCHK(hipMalloc(&seq.p, n + 16));
+        if (n) {
+            HIPCHK(prf_launch_lit_unpack(c->stream, g->H, g->L, g->X, g->E, g->base[ci] + lo, n, (uint8_t *)seq.p));
+            launches++;
+        }
+        const size_t at = rows.size();
+        const int rc = literal_device(c, (uint8_t *)seq.p, n, false, (u32)ci, kmin, kmax, min_repeats, min_span, n, rows, &ms, &launches);
+        if (rc) return rc;
+        for (size_t r = at; r < rows.size(); r++) {
+            rows[r].start += lo;
+            rows[r].end += lo;
+        }
+    }
+    return literal_finish(c, rows, ms, launches, g->positions, out, stats);
+}
+
 static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, const u64 *stops, u32 kmin, u32 kmax, u32 min_repeats,
                         u32 min_span, prf_hits *out, prf_scan_stats *stats) {
     if (!c) return fail(PRF_EINVAL, "prf_scan_literal: NULL context");
@@ -907,7 +985,7 @@ static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, co
     if (min_span < 1) return fail(PRF_EINVAL, "min_span is set to %u. It must be at least 1.", min_span);
     if (kmax > 60000) return fail(PRF_EUNSUPPORTED, "max_motif_size %u > 60000", kmax);
     if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
-    if (c->async_n) return fail(PRF_EINVAL, "prf_scan_literal: pipelined scans are in flight on this context");
+    if (c->slot[0].seq || c->slot[1].seq) return fail(PRF_EINVAL, "prf_scan_literal: pipelined scans are in flight on this context");
     HIPCHK(hipSetDevice(c->dev));
     std::vector<prf_hit> rows;
     float ms = 0;
@@ -935,24 +1013,7 @@ static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, co
         }
         positions += contigs[i].len;
     }
-    c->last_nhits = 0;  // the rows of this lane live on the host only
-    c->last_rows = nullptr;
-    if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->scan_ms = stats->phase1_ms = ms;
-        stats->positions = positions;
-        stats->packed_bytes = positions;  // this lane reads the bytes themselves
-        stats->n_candidates = stats->n_hits = rows.size();
-        stats->n_launches = launches;
-        stats->path = 2;
-    }
-    if (!out || rows.empty()) return PRF_OK;
-    prf_hit *r = (prf_hit *)malloc(rows.size() * sizeof(prf_hit));
-    if (!r) return fail(PRF_ENOMEM, "prf_scan_literal: cannot allocate %zu rows", rows.size());
-    memcpy(r, rows.data(), rows.size() * sizeof(prf_hit));
-    out->rows = r;
-    out->n = rows.size();
-    return PRF_OK;
+    return literal_finish(c, rows, ms, launches, positions, out, stats);
 }
 
 int prf_scan_literal(prf_ctx *c, const prf_contig *contig, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,

@@ -45,3 +45,8 @@ hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, c
 hipError_t prf_launch_lit_upper(hipStream_t s, uint8_t *seq, u64 n, u64 *bad_pos);
 hipError_t prf_launch_lit_events(hipStream_t s, const uint8_t *seq, u64 L, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
                                  u64 stop, u32 contig, prf_hit_dev *rows, u64 cap, u64 *counters);
+// the same lane on a resident genome: first / one-past-last position of a contig that is not N (atomicMin / atomicMax into
+// first_last[0..1]); the upper-cased bytes of n positions from global position g0 rebuilt from the linear planes
+hipError_t prf_launch_lit_trim(hipStream_t s, const u64 *X, const u64 *const *E, u64 word0, u64 len, u64 *first_last);
+hipError_t prf_launch_lit_unpack(hipStream_t s, const u64 *H, const u64 *L, const u64 *X, const u64 *const *E, u64 g0, u64 n,
+                                 uint8_t *out);

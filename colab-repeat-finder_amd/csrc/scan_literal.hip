@@ -127,7 +127,66 @@ __global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__re
     }
 }
 
+struct lit_codes {
+    const u64 *e[5];  // code planes of the symbols outside ACGTN (prf_planes::E); e[0] == nullptr: the genome has none
+};
+
+// first / one-past-last position of a contig that is not N: one thread per 64-position word of the X plane
+__global__ void prf_lit_trim_kernel(const u64 *__restrict__ X, lit_codes E, u64 word0, u64 len, u64 *__restrict__ first_last) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 64 >= len) return;
+    u64 is_n = X[word0 + w];  // not ACGT ...
+    if (E.e[0]) is_n &= ~(E.e[0][word0 + w] | E.e[1][word0 + w] | E.e[2][word0 + w] | E.e[3][word0 + w] | E.e[4][word0 + w]);  // ... and no other letter
+    u64 other = ~is_n;
+    const u64 left = len - w * 64;
+    if (left < 64) other &= (1ull << left) - 1ull;
+    if (!other) return;
+    const u64 first = w * 64 + (u64)__builtin_ctzll(other), last = w * 64 + 64 - (u64)__builtin_clzll(other);
+    // most words improve neither bound: look before the atomic
+    if (first < __atomic_load_n(&first_last[0], __ATOMIC_RELAXED)) atomicMin(&first_last[0], first);
+    if (last > __atomic_load_n(&first_last[1], __ATOMIC_RELAXED)) atomicMax(&first_last[1], last);
+}
+
+// upper-cased bytes of positions g0 .. g0+n-1 (global coordinate space) from the planes: H, L = bits 2 and 1 of the letter
+// for A, C, G, T (pack.hip); X = not ACGT: the letter with the five-bit code of the E planes, or N where the code is 0
+__global__ void prf_lit_unpack_kernel(const u64 *__restrict__ H, const u64 *__restrict__ L, const u64 *__restrict__ X, lit_codes E,
+                                      u64 g0, u64 n, uint8_t *__restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const u64 q = g0 + p, w = q >> 6;
+        const unsigned b = (unsigned)(q & 63);
+        uint8_t ch;
+        if (!((X[w] >> b) & 1ull)) {
+            const unsigned h = (unsigned)((H[w] >> b) & 1ull), l = (unsigned)((L[w] >> b) & 1ull);
+            ch = h ? (l ? 'G' : 'T') : (l ? 'C' : 'A');
+        } else {
+            unsigned code = 0;
+            if (E.e[0])
+                for (int i = 0; i < 5; i++) code |= (unsigned)((E.e[i][w] >> b) & 1ull) << i;
+            ch = code ? (uint8_t)('@' + code) : (uint8_t)'N';
+        }
+        out[p] = ch;
+    }
+}
+
 }  // namespace
+
+hipError_t prf_launch_lit_trim(hipStream_t st, const u64 *X, const u64 *const *E, u64 word0, u64 len, u64 *first_last) {
+    lit_codes codes{{E[0], E[1], E[2], E[3], E[4]}};
+    const u64 words = (len + 63) / 64;
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(prf_lit_trim_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, X, codes, word0, len, first_last);
+    return hipGetLastError();
+}
+
+hipError_t prf_launch_lit_unpack(hipStream_t st, const u64 *H, const u64 *L, const u64 *X, const u64 *const *E, u64 g0, u64 n,
+                                 uint8_t *out) {
+    lit_codes codes{{E[0], E[1], E[2], E[3], E[4]}};
+    if (!n) return hipSuccess;
+    const u64 blocks = (n + 256ull * 8 - 1) / (256ull * 8);
+    hipLaunchKernelGGL(prf_lit_unpack_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, st, H, L, X, codes, g0, n, out);
+    return hipGetLastError();
+}
 
 hipError_t prf_launch_lit_upper(hipStream_t st, uint8_t *s, u64 n, u64 *bad_pos) {
     if (n == 0) return hipSuccess;

@@ -41,7 +41,7 @@ typedef enum prf_status {
     PRF_ENODEV = -2,       /* no HIP device / wrong architecture                                          */
     PRF_EHIP = -3,         /* a HIP runtime call failed (see prf_last_error)                              */
     PRF_ENOMEM = -4,       /* host or device allocation failed                                            */
-    PRF_EUNSUPPORTED = -5, /* this entry point does not serve the regime (min_repeats == 1 on a packed genome; kmax > hint) */
+    PRF_EUNSUPPORTED = -5, /* this entry point does not serve the regime (kmax > hint; min_repeats == 1 on parts of a genome) */
     PRF_ESYMBOL = -6,      /* a byte that is not a letter: refused loudly, never guessed                  */
     PRF_EINDEX = -7        /* the reference raises IndexError on this input (utils/perfect_repeat_tracker.py:87: the
                             * extension loop's seq[i+1-period] reaches in front of the sequence; only with min_repeats == 1
@@ -141,9 +141,11 @@ int prf_genome_select(prf_genome *g, const prf_part *parts, int n_parts);
 int prf_genome_tile_classes(const prf_genome *g, uint32_t contig, uint8_t *dst, uint64_t capacity, uint64_t *n_tiles);
 
 /* The hot path on a resident genome: every k in [kmin,kmax], rows as reference :81.
- * Requires min_repeats >= 2 (PRF_EUNSUPPORTED otherwise: with min_repeats == 1 the reference's rows depend on the text in
- * front of a run and on Python's negative-index wrap-around, which the packed planes with their guard gaps do not keep;
- * prf_scan() and prf_scan_literal() serve that regime from the sequence bytes). */
+ * min_repeats == 1 (outside the closed form of the packed kernels: the reference's rows then depend on the text in front of
+ * a run, on where the sequence begins and ends and on Python's negative-index wrap-around) is served by the literal lane:
+ * the upper-cased bytes of every contig are rebuilt on the device from the planes, trimmed of the N at both ends (reference
+ * :40-46) and scanned as prf_scan_literal() does; whole contigs only (PRF_EUNSUPPORTED while a selection of parts or a row
+ * sink is set), rows on the host only (prf_last_hits_* then have nothing to hand over), PRF_EINDEX as there. */
 int prf_scan_genome(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
                     uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
 

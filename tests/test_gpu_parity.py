@@ -106,6 +106,13 @@ def test_literal_lane_vs_oracle_and_vs_packed_kernels(ctx):
     for i, cs in enumerate(contigs):
         want = [(s, e, ml) for s, e, ml, _k in prf_oracle.detect_rows(cs, 1, 8, 1, 5)]
         assert got.get(i, []) == want, i
+    # (d) the same on a RESIDENT genome (prf_scan_genome): the bytes are rebuilt on the device from the packed planes
+    g = ctx.load(contigs, 8)
+    try:
+        rows_g, stats_g = g.scan(1, 8, 1, 5)
+        assert stats_g.path == 2 and rows_as_tuples(rows_g) == rows_as_tuples(rows) and len(rows_g) > 100
+    finally:
+        g.free()
 
 
 def test_adversarial(detect, golden_adversarial):
@@ -316,11 +323,15 @@ def test_errors_cross_the_boundary_cleanly(ctx):
     assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
     rows, _ = ctx.scan([b"ACGTRYACGT"], 1, 5, 3, 9)          # IUPAC letters are ordinary symbols (see the test below)
     assert len(rows) == 0
-    g = ctx.load([b"ACGT"], 5)
+    g = ctx.load([b"ACGT" * 40000], 5)
     try:
-        with pytest.raises(prf_native.PrfError) as info:     # min_repeats == 1 needs the sequence bytes (literal lane), not packed planes
+        g.select([(0, 0, 65536)])
+        with pytest.raises(prf_native.PrfError) as info:     # min_repeats == 1 scans whole contigs: not with a selection of parts
             g.scan(1, 5, 1, 9)
         assert info.value.code == prf_native.PRF_EUNSUPPORTED
+        g.select([])
+        rows, stats = g.scan(1, 5, 1, 9)
+        assert rows_as_tuples(rows) == [(0, 0, 160000, 4)] and stats.path == 2
     finally:
         g.free()
     rows, stats = ctx.scan([b"ACGT"], 1, 5, 1, 9)            # prf_scan serves it on the literal lane
