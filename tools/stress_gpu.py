@@ -66,7 +66,14 @@ while time.time() < t_end:
     except IndexError:
         want = 'IndexError'
     try:
-        rows, st = ctx.scan(small, kmin, kmax, 1, span)
+        if rng.random() < 0.5:
+            rows, st = ctx.scan(small, kmin, kmax, 1, span)
+        else:                                    # the same on a resident genome: bytes rebuilt on the device from the planes
+            gs = ctx.load(small, kmax)
+            try:
+                rows, st = gs.scan(kmin, kmax, 1, span)
+            finally:
+                gs.free()
         got = [(int(x['contig']), int(x['start']), int(x['end']), int(x['k'])) for x in rows]
     except prf_native.PrfError as exc:
         got = 'IndexError' if exc.code == prf_native.PRF_EINDEX else repr(exc)
