@@ -832,8 +832,9 @@ int prf_scan_genome(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kma
 
 // ---- the literal lane (scan_literal.hip): regimes outside the closed form ----
 // One sequence at a time, straight from its ASCII bytes (upper-cased on the device): one thread per (position, motif size)
-// evaluates the reference's flush call as written; the host keeps the shortest motif per (start, end), which is what the
-// reference's dictionary holds at the end (utils/perfect_repeat_tracker.py:93-101), and sorts like reference :81.
+// evaluates the reference's flush call as written; the rows are then sorted like reference :81 and reduced to the shortest
+// motif per (start, end) -- what the reference's dictionary holds at the end (utils/perfect_repeat_tracker.py:93-101) -- on the
+// device as well (prf_lit_sort_unique).
 namespace {
 struct dev_free {
     void *p = nullptr;
@@ -846,7 +847,6 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
                           u32 min_span, u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
     if (stop > L) stop = L;
     dev_free rows;
-    struct { uint8_t *p; } seq{d_seq};
     u64 cap = L / 16 + 4096;
     u64 *h = c->h_counters;
     for (int attempt = 0;; attempt++) {
@@ -854,8 +854,8 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
         HIPCHK(hipMemsetAsync(c->d_counters, 0, PRF_CNT_N * sizeof(u64), c->stream));
         HIPCHK(hipMemsetAsync(c->d_counters + PRF_CNT_BADPOS, 0xFF, sizeof(u64), c->stream));
         HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        if (attempt == 0 && upper) HIPCHK(prf_launch_lit_upper(c->stream, (uint8_t *)seq.p, L, c->d_counters + PRF_CNT_BADPOS));
-        HIPCHK(prf_launch_lit_events(c->stream, (const uint8_t *)seq.p, L, kmin, kmax, min_repeats, min_span, stop, contig_index,
+        if (attempt == 0 && upper) HIPCHK(prf_launch_lit_upper(c->stream, d_seq, L, c->d_counters + PRF_CNT_BADPOS));
+        HIPCHK(prf_launch_lit_events(c->stream, d_seq, L, kmin, kmax, min_repeats, min_span, stop, contig_index,
                                      (prf_hit_dev *)rows.p, cap, c->d_counters));
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
         HIPCHK(hipMemcpyAsync(h, c->d_counters, PRF_CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -873,21 +873,26 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
             return fail(PRF_EINDEX, "string index out of range");  // the message of Python's IndexError (tracker :87)
         const u64 n = h[PRF_CNT_HITS];
         if (n <= cap) {
-            const size_t at = rows_out.size();
-            rows_out.resize(at + n);
+            // sorted by (start, end) and reduced to the shortest motif per (start, end) on the device (scan_literal.hip)
             static_assert(sizeof(prf_hit) == sizeof(prf_hit_dev), "row layouts must agree");
             if (n) {
-                HIPCHK(hipMemcpyAsync(rows_out.data() + at, rows.p, n * sizeof(prf_hit), hipMemcpyDeviceToHost, c->stream));
+                dev_free uniq;
+                HIPCHK(hipMalloc(&uniq.p, n * sizeof(prf_hit_dev)));
+                u64 *d_n = c->d_counters + PRF_CNT_HITS;  // read above; reused for the number of rows that stay
+                HIPCHK(prf_lit_sort_unique(c->stream, (const prf_hit_dev *)rows.p, n, (prf_hit_dev *)uniq.p, d_n));
+                HIPCHK(hipMemcpyAsync(h, d_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
+                const u64 kept = h[0];
+                if (kept > n) return fail(PRF_EHIP, "prf_scan_literal: row compaction returned %llu of %llu rows", (unsigned long long)kept,
+                                          (unsigned long long)n);
+                const size_t at = rows_out.size();
+                rows_out.resize(at + kept);
+                if (kept) {
+                    HIPCHK(hipMemcpyAsync(rows_out.data() + at, uniq.p, kept * sizeof(prf_hit), hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                }
+                *launches += 5;
             }
-            std::sort(rows_out.begin() + at, rows_out.end(), [](const prf_hit &a, const prf_hit &b) {
-                if (a.start != b.start) return a.start < b.start;
-                if (a.end != b.end) return a.end < b.end;
-                return a.k < b.k;
-            });
-            auto last = std::unique(rows_out.begin() + at, rows_out.end(),
-                                    [](const prf_hit &a, const prf_hit &b) { return a.start == b.start && a.end == b.end; });
-            rows_out.erase(last, rows_out.end());
             return PRF_OK;
         }
         if (attempt >= 2) return fail(PRF_EHIP, "prf_scan_literal: the row count changed between two runs");
@@ -938,7 +943,8 @@ static int literal_genome(prf_ctx *c, const prf_genome *g, u32 kmin, u32 kmax, u
     if (g->sel_on)
         return fail(PRF_EUNSUPPORTED, "min_repeats == 1 scans whole contigs (its rows depend on where a sequence begins and ends): "
                                       "clear the selection of parts (prf_genome_select with n_parts == 0)");
-    if (c->sink) return fail(PRF_EUNSUPPORTED, "min_repeats == 1: not with a row sink (the rows of the literal lane are deduplicated on the host)");
+    if (kmax > 60000) return fail(PRF_EUNSUPPORTED, "max_motif_size %u > 60000", kmax);
+    if (c->sink) return fail(PRF_EUNSUPPORTED, "min_repeats == 1: not with a row sink (the rows of the literal lane are handed over on the host)");
     if (c->slot[0].seq || c->slot[1].seq) return fail(PRF_EINVAL, "prf_scan_genome: pipelined scans are in flight on this context");
     std::vector<prf_hit> rows;
     float ms = 0;

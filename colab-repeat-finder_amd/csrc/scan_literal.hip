@@ -15,10 +15,12 @@
 //   seq[i+1-k] with Python's negative-index wrap-around and its IndexError (:87-89), the second filter (:91), the
 //   primitive-motif test (:98, :108-142) -- and appends (start, end, len(motif)) to the row array.
 //
-// The host then keeps, per (start, end), the row with the shortest motif slice.  Work is one byte compare per
+// prf_lit_sort_unique() then sorts the rows and keeps, per (start, end), the one with the shortest motif slice (on the device).  Work is one byte compare per
 // (i, k) plus O(run) per event: HBM/L2-bound byte work, nothing to tile.  It is the slow lane on purpose -- the default
 // regime (min_repeats >= 2, whole sequences) never comes here.
 #include "prf_host.h"
+
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -186,6 +188,80 @@ hipError_t prf_launch_lit_unpack(hipStream_t st, const u64 *H, const u64 *L, con
     const u64 blocks = (n + 256ull * 8 - 1) / (256ull * 8);
     hipLaunchKernelGGL(prf_lit_unpack_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, st, H, L, X, codes, g0, n, out);
     return hipGetLastError();
+}
+
+// ---- rows of the event kernel -> sorted by (start, end), one row per (start, end): the shortest motif ----
+// What the reference's dictionary and its sorted() leave (utils/perfect_repeat_tracker.py:93-101, perfect_repeat_finder.py:81),
+// on the device: two stable radix sorts of row indices (by (end, motif length), then by start), a gather that flags the first
+// row of every (start, end) group, and a flagged compaction.
+namespace {
+__global__ void prf_lit_key_end_kernel(const prf_hit_dev *__restrict__ rows, u64 n, u64 *__restrict__ key, u32 *__restrict__ idx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = (rows[i].end << 16) | (u64)(rows[i].k & 0xffffu);  // end < 2^41, motif length <= 60000
+    idx[i] = (u32)i;
+}
+__global__ void prf_lit_key_start_kernel(const prf_hit_dev *__restrict__ rows, u64 n, const u32 *__restrict__ idx, u64 *__restrict__ key) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = rows[idx[i]].start;
+}
+__global__ void prf_lit_gather_kernel(const prf_hit_dev *__restrict__ rows, u64 n, const u32 *__restrict__ idx,
+                                      prf_hit_dev *__restrict__ sorted, unsigned char *__restrict__ first) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const prf_hit_dev r = rows[idx[i]];
+    sorted[i] = r;
+    bool f = true;
+    if (i) {
+        const prf_hit_dev q = rows[idx[i - 1]];
+        f = q.start != r.start || q.end != r.end;
+    }
+    first[i] = f ? 1 : 0;
+}
+}  // namespace
+
+// rows[0..n) -> out[0..*n_out) (device memory, n_out a device word); scratch allocated and freed here (the slow lane)
+hipError_t prf_lit_sort_unique(hipStream_t st, const prf_hit_dev *rows, u64 n, prf_hit_dev *out, u64 *n_out) {
+    if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(u64), st);
+    if (n > 0x7fffffffull) return hipErrorInvalidValue;
+    const int ni = (int)n;
+    u64 *key_a = nullptr, *key_b = nullptr;
+    u32 *idx_a = nullptr, *idx_b = nullptr;
+    prf_hit_dev *sorted = nullptr;
+    unsigned char *first = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_sort = 0, tmp_sel = 0;
+    hipError_t e = hipSuccess;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    step(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key_a, key_b, idx_a, idx_b, ni, 0, 64, st));
+    step(hipcub::DeviceSelect::Flagged(nullptr, tmp_sel, sorted, first, out, n_out, ni, st));
+    const size_t tmp_bytes = tmp_sort > tmp_sel ? tmp_sort : tmp_sel;
+    step(hipMalloc((void **)&key_a, n * 8));
+    step(hipMalloc((void **)&key_b, n * 8));
+    step(hipMalloc((void **)&idx_a, n * 4));
+    step(hipMalloc((void **)&idx_b, n * 4));
+    step(hipMalloc((void **)&sorted, n * sizeof(prf_hit_dev)));
+    step(hipMalloc((void **)&first, n));
+    step(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    if (e == hipSuccess) {
+        size_t b = tmp_bytes;
+        hipLaunchKernelGGL(prf_lit_key_end_kernel, dim3(nb), dim3(256), 0, st, rows, n, key_a, idx_a);
+        step(hipGetLastError());
+        step(hipcub::DeviceRadixSort::SortPairs(tmp, b, key_a, key_b, idx_a, idx_b, ni, 0, 58, st));   // by (end, motif length)
+        hipLaunchKernelGGL(prf_lit_key_start_kernel, dim3(nb), dim3(256), 0, st, rows, n, idx_b, key_a);
+        step(hipGetLastError());
+        b = tmp_bytes;
+        step(hipcub::DeviceRadixSort::SortPairs(tmp, b, key_a, key_b, idx_b, idx_a, ni, 0, 42, st));   // stable: by start, ties keep (end, length)
+        hipLaunchKernelGGL(prf_lit_gather_kernel, dim3(nb), dim3(256), 0, st, rows, n, idx_a, sorted, first);
+        step(hipGetLastError());
+        b = tmp_bytes;
+        step(hipcub::DeviceSelect::Flagged(tmp, b, sorted, first, out, n_out, ni, st));
+        step(hipStreamSynchronize(st));  // the scratch is freed below
+    }
+    (void)hipFree(key_a); (void)hipFree(key_b); (void)hipFree(idx_a); (void)hipFree(idx_b);
+    (void)hipFree(sorted); (void)hipFree(first); (void)hipFree(tmp);
+    return e;
 }
 
 hipError_t prf_launch_lit_upper(hipStream_t st, uint8_t *s, u64 n, u64 *bad_pos) {
