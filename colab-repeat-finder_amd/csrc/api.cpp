@@ -93,7 +93,8 @@ struct prf_ctx {
     prf_hit_dev *d_hits_async = nullptr;
     u64 hit_cap_async = 0;
     // fused (bit-sliced) path scratch: one row slab and one row count per launch slot (= scanned tile)
-    prf_hit_dev *d_slabs = nullptr;
+    u64 *d_slabs = nullptr;         // 8-byte rows (scan_vertical.h)
+    u64 *d_long_ends = nullptr;     // per launch slot: true ends of the rows whose span is clipped in the 8-byte form
     u32 *d_slab_count = nullptr;
     u32 *d_block_sum = nullptr;     // rows per PRF_GATHER_SLOTS launch slots; zero between scans (the gather clears it)
     u64 slab_slots = 0;
@@ -203,6 +204,7 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_slabs);
+    (void)hipFree(c->d_long_ends);
     (void)hipFree(c->d_slab_count);
     (void)hipFree(c->d_block_sum);
     for (auto &ev : c->ev)
@@ -494,15 +496,18 @@ static int ensure_slabs(prf_ctx *c, u64 nslots, u32 cap) {
         cap = std::max<u32>(cap, c->slab_cap);
         HIPCHK(hipStreamSynchronize(c->stream));  // no scan in flight may still use the old buffers
         (void)hipFree(c->d_slabs);
+        (void)hipFree(c->d_long_ends);
         (void)hipFree(c->d_slab_count);
         (void)hipFree(c->d_block_sum);
         c->d_slabs = nullptr;
+        c->d_long_ends = nullptr;
         c->d_slab_count = nullptr;
         c->d_block_sum = nullptr;
         c->slab_slots = 0;
         c->slab_cap = 0;
         const size_t n_blocks = (size_t)(nslots / 8 + 1) + 2 * (size_t)(nslots / (8 * PRF_GATHER_SUPER) + 2);
-        HIPCHK(hipMalloc((void **)&c->d_slabs, nslots * (u64)cap * sizeof(prf_hit_dev)));
+        HIPCHK(hipMalloc((void **)&c->d_slabs, nslots * (u64)cap * sizeof(u64)));
+        HIPCHK(hipMalloc((void **)&c->d_long_ends, nslots * (u64)PRF_LONG_PER_TILE * sizeof(u64)));
         HIPCHK(hipMalloc((void **)&c->d_slab_count, nslots * sizeof(u32)));
         HIPCHK(hipMalloc((void **)&c->d_block_sum, n_blocks * sizeof(u32)));
         HIPCHK(hipMemset(c->d_block_sum, 0, n_blocks * sizeof(u32)));
@@ -522,7 +527,7 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     a.H = g->H; a.L = g->L; a.X = g->X;
     a.E = g->d_E;
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
-    a.slabs = c->d_slabs; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
+    a.slabs = c->d_slabs; a.long_ends = c->d_long_ends; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
     // the gather takes 8 launch slots per workgroup on small launches (more workgroups in flight), 64 on large ones
     a.gather_shift = lv.n <= 8192u ? 3u : 6u;
     {   // PRF_GATHER_SHIFT (diagnostic): launch slots per gather workgroup = 1 << shift, 3 .. 6
@@ -549,7 +554,8 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
 #endif
     a.plan = plan;
     prf_vgather_args ga;
-    ga.slabs = c->d_slabs; ga.slab_count = c->d_slab_count; ga.block_sum = c->d_block_sum; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
+    ga.slabs = c->d_slabs; ga.long_ends = c->d_long_ends; ga.launch_list = lv.list; ga.flat_base = lv.flat; ga.tile_info = g->d_tile_info;
+    ga.slab_count = c->d_slab_count; ga.block_sum = c->d_block_sum; ga.slab_cap = c->slab_cap; ga.n_launch = lv.n;
     ga.super_off = a.super_off;
     ga.gather_shift = a.gather_shift;
     ga.rows = rows; ga.rows_cap = rows_cap; ga.count_row = count_row;
@@ -603,7 +609,9 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
     const launch_view lv = active_launch(g);
     u64 want_cand = std::max<u64>(c->cand_cap, lv.positions / 8 + 65536);
     u64 want_hits = std::max<u64>(c->hit_cap, lv.positions / 32 + 65536);
-    u32 slab_cap = std::max<u32>(c->slab_cap, 320u);
+    // rows per tile the slabs hold (8 bytes each): the densest 65536-position tile of the reference's golden chr22 BED has 748
+    // rows at motif sizes 1-6; a tile beyond the capacity grows the slabs and scans again
+    u32 slab_cap = std::max<u32>(c->slab_cap, 1024u);
     float ms01 = 0, ms12 = 0;
     u64 ncand = 0, nhits = 0;
     u32 launches = 0;
@@ -689,6 +697,9 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 fprintf(stderr, "[prf] fused: hits %llu cand-records %llu hit_ovf %llu unsorted %llu ms %.4f\n", (unsigned long long)nhits,
                         (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF],
                         (unsigned long long)c->h_counters[PRF_CNT_UNSORTED], ms01);
+            if (c->h_counters[PRF_CNT_LONG_OVF])
+                return fail(PRF_EHIP, "internal: a tile reported %llu rows longer than 65534 positions (at most %u can exist)",
+                            (unsigned long long)c->h_counters[PRF_CNT_LONG_OVF], PRF_LONG_PER_TILE);
             const u64 hit_ovf = c->h_counters[PRF_CNT_HIT_OVF];
             if (hit_ovf > c->slab_cap) { slab_cap = (u32)std::min<u64>(hit_ovf + hit_ovf / 4 + 64, 1u << 22); again = true; }
             if (!again && c->sink && nhits > c->sink_cap)
@@ -1132,7 +1143,7 @@ int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
     const u64 nhits = sl->h[PRF_CNT_ROWS];
     u64 ncand = 0;
     for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) ncand += sl->h[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
-    if (sl->h[PRF_CNT_HIT_OVF] > c->slab_cap || nhits > c->hit_cap)
+    if (sl->h[PRF_CNT_HIT_OVF] > c->slab_cap || nhits > c->hit_cap || sl->h[PRF_CNT_LONG_OVF])
         return fail(PRF_EUNSUPPORTED, "prf_scan_wait: the buffers sized by the last synchronous scan overflowed; scan synchronously");
     c->last_nhits = nhits;
     c->last_rows = sl->rows;

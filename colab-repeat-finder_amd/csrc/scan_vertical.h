@@ -53,19 +53,28 @@ struct prf_vplan {
     u32 k_exact0;
     u32 ticket_wave;                            // the wave whose first lane draws the workgroup's next launch slot (it waits for the atomic)
     u32 slack_waves;                            // bit w: wave w's scan work is < 90 % of the busiest wave's
+    u32 per_cu;                                 // workgroups per CU the plan's LDS and the kernel's registers allow
     u32 prio;                                   // issue priorities (s_setprio), 2 bits each: stage | scan, busy wave << 2 | scan, slack
                                                 // wave << 4 | verify, flag waves << 6 | verify, record waves << 8 | rows << 10
 };
+
+// One row as the scan kernel leaves it in its tile's slab: 8 bytes.
+//   [15:0]  span = end - start, clipped to 65535     [31:16] start - first position of the tile
+//   [47:32] motif size                               [50:48] 0, or 1 + index of the row's true end among the tile's
+//                                                            long ends (span >= 65535: at most two rows of a tile, Fine and Wilf)
+// Sorted by the low word = by (start, end).  The gather kernel turns them into 24-byte prf_hit_dev rows.
+#define PRF_LONG_PER_TILE 4u
 
 // everything the fused kernel needs (passed by value)
 struct prf_vscan_args {
     const u32 *VH, *VL, *VX;       // bit-sliced planes
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
     const u64 *const *E;           // device array of the five planes of the symbols outside ACGTN, or nullptr
-    const u32 *launch_list;        // tiles in position order (PRF_LAUNCH_MIXED flags); one workgroup per entry
+    const u32 *launch_list;        // tiles in position order (PRF_LAUNCH_MIXED flags); one launch slot per entry
     u32 n_launch;
     u32 flat_base;                 // != ~0u: entry i is the clean tile flat_base + i (no dependent load)
-    prf_hit_dev *slabs;            // [launch slot][slab_cap]: the tile's rows, sorted by (start, end)
+    u64 *slabs;                    // [launch slot][slab_cap]: the tile's rows (8 bytes each), sorted by (start, end)
+    u64 *long_ends;                // [launch slot][PRF_LONG_PER_TILE]: true ends (global positions) of the rows whose span is clipped
     u32 *slab_count;               // [launch slot]: rows the tile produced (> slab_cap: the slab overflowed)
     u32 *block_sum;                // [launch slot >> gather_shift]: rows stored by those slots (zero when the kernel starts);
     u32 super_off;                 // from block_sum[super_off] on: the same per PRF_GATHER_SUPER gather workgroups, then their tickets
@@ -78,10 +87,14 @@ struct prf_vscan_args {
     prf_vplan plan;
 };
 
-// the row gather: slabs in launch order -> one compact array, counters -> host
+// the row gather: slabs in launch order -> one compact array of 24-byte rows, counters -> host
 struct prf_vgather_args {
-    const prf_hit_dev *slabs;
+    const u64 *slabs;
+    const u64 *long_ends;
     const u32 *slab_count;
+    const u32 *launch_list;        // as in prf_vscan_args: the tile of a launch slot
+    u32 flat_base;
+    const uint4 *tile_info;
     u32 *block_sum;                // read, then cleared by the last workgroup
     u32 super_off;
     u32 gather_shift;

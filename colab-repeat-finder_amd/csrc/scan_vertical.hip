@@ -17,28 +17,37 @@
 // access and a wave reads 1 KiB contiguously; the LDS image has the same shape with 64+J lanes.
 // The shift by k therefore costs no instruction: it is an LDS address.
 //
-// One 256-thread workgroup per tile:
-//  1. stage: the tile's bit-sliced planes and a window of the LINEAR H/L planes (tile - 64 .. tile + 65536 +
-//     1536 positions) go to LDS.
+// One 256-thread workgroup per tile, SIX resident per CU (round 3; four before): <= 80 VGPRs and <= 27.3 KB of LDS.
+// What made room: ONE 18 KB region R1 is the bit-sliced image while the tile is scanned and the window of the linear
+// planes while its candidates are verified (before: two regions, 35 KB); both are filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass), the next tile's image while this tile's rows are
+// sorted; the exact tasks slide over the stream with a window of K + 4 rows in registers instead of all 60.
+//  1. stage: the image arrived by DMA; 128 threads add the virtual lanes 64.. (one shift/or of two prefetched slots).
 //  2. scan: every wave runs its share of the plan's tasks (host-built, balanced by cost).  A task answers one
 //     question per (stream, motif size): "may a reportable run be found from this stream?" --
-//      * exact task, one motif size k <= 14 with M(k) = M < 15 (compiled per (k, M)): the whole stream in one
-//        straight-line block: mismatch word per row (2 operations), sliding OR over exactly M rows; a row whose
-//        M successors all match and whose predecessor does not is the start of a run of >= M.
+//      * exact task, one motif size k <= 14 with M(k) = M < 15 (compiled per (k, M)): mismatch word per row
+//        (2 operations), sliding OR over exactly M rows; a row whose M successors all match and whose predecessor
+//        does not is the start of a run of >= M.
 //      * group task, 8 motif sizes k0..k0+7 with M(k) >= 15: a run of >= 15 matches contains an aligned
 //        group of 8 rows that all match.  Per (group, k) the 8 rows of (H^H')|(L^L') are OR-ed with 16
 //        v_bitop3_b32; motif sizes with M >= 23 / 39 examine only every 2nd / 4th group.
-//     The answer is ONE 32-bit word per lane, task and motif size (bit b = stream b*64+lane); lanes with a
-//     non-zero word append an 8-byte record (lane, k, word) to their wave's LDS list.  No bit loop, no atomics.
-//  3. verify: all lanes expand the records; for every flagged (stream, k) the candidates are re-derived EXACTLY
-//     from the linear planes (64-position looks, verify_impl.h) and each becomes a row or nothing.  A row belongs
+//     The answer is ONE 32-bit word per lane, task and motif size (bit b = stream b*64+lane).
+//     A tile with not-ACGT positions in reach ("mixed") is scanned on the same two planes, where such a position reads
+//     as A: that can only add matches, so with the flag rule relaxed to "M matching rows start in this stream" (exact)
+//     and "an all-match group lies in this stream" (group) no stream that holds a row is missed; the streams that
+//     consist of nothing but N are masked out (they cannot hold the start of a run).  False flags cost time only.
+//  3. verify: R1 is refilled with the window of the linear planes H and L (tile - 128 .. tile + 65536 + 1536
+//     positions); for every flagged (stream, k) the candidates are re-derived EXACTLY from the linear planes -- a
+//     mixed tile reads the not-ACGT plane from global memory -- and each becomes a row or nothing.  A row belongs
 //     to the tile that holds its first position: a run whose first examined group lies in the next tile is
 //     reported by a look at the tile's end (boundary pass), and dropped by the next tile.
-//  4. rows: sorted by (start, end) in LDS, written to the tile's slab.
-// A second, small kernel (prf_vgather_kernel) concatenates the slabs in launch (= position) order: the row array
-// leaves the device sorted by (contig, start, end), which is what the reference's sorted() returns (:81).
+//  4. rows: sorted by (start, end) in LDS, written to the tile's slab as 8-byte rows.
+// A second, small kernel (prf_vgather_kernel) concatenates the slabs in launch (= position) order and expands the
+// rows to 24 bytes: the row array leaves the device sorted by (contig, start, end), which is what the reference's
+// sorted() returns (:81).
 // Exactness argument: DESIGN.md.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -51,15 +60,18 @@ namespace {
 
 constexpr int T = 32;      // rows (= positions) per stream
 constexpr int RG = T / 4;  // row groups of 4 rows = one 16-byte slot per lane
-constexpr int LIN_PRE = 1;                                    // linear window: words before the tile
+constexpr int LIN_PRE = 2;                                    // linear window: words before the tile (even: 16-byte DMA pieces)
 constexpr int LIN_POST = 24;                                  // ... and after it
 constexpr int LW = (int)PRF_TILE_WORDS + LIN_PRE + LIN_POST;  // words per plane in the LDS window
-constexpr int REC_PER_WAVE = 96;                              // group-task candidate records per wave (LDS list)
+static_assert(LW % 2 == 0, "the window travels in 16-byte pieces");
+constexpr u32 WIN_LEAD = 64u * (u32)LIN_PRE;                  // window positions in front of the tile
+constexpr int REC_CAP = 256;                                  // group-task candidate records of a tile (one LDS list)
 constexpr int MAX_WAVES = PRF_VMAX_WAVES;
 constexpr int NTH = 64 * MAX_WAVES;                           // threads per workgroup, always
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
 constexpr u32 FLAGS_PER_TASK = 128;                           // flags (lane, stream) an exact task's list holds: 256 B per task
-constexpr int ROW_CAP_LDS = 256;                              // rows of a tile sorted in LDS (more: unsorted, host sorts)
+constexpr int ROW_CAP_LDS = 448;                              // rows of a tile in the LDS list (more: the slab holds the rest, sorted in R1)
+static_assert(ROW_CAP_LDS % 32 == 0, "the rank loop reads the padded key list 32 keys at a time");
 
 template <int A, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -71,17 +83,20 @@ __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B > A) static_for_impl<A>(static_cast<F &&>(f), std::make_integer_sequence<int, B - A>{});
 }
 
-// ---- candidate records: [5:0] lane, [14:6] k, [16:15] 0 = exact task, 1/2/3 = group task examining every 1st/2nd/4th
-// group, [48:17] stream word (bit b = stream b*64 + lane may hold a candidate) ----
+// ---- group-task candidate records: [5:0] lane, [14:6] k, [16:15] 1/2/3 = every 1st/2nd/4th group examined,
+// [48:17] stream word (bit b = stream b*64 + lane may hold a candidate) ----
 __device__ __forceinline__ u64 make_rec(u32 lane, u32 k, u32 sc, u32 word) {
     return (u64)(lane | (k << 6) | (sc << 15)) | ((u64)word << 17);
 }
 
-// dynamic LDS: [header 192 B][vimg: 2*RG*NC uint4][lin: 2*LW u64][recs: MAX_WAVES*REC_PER_WAVE u64]
-// A tile with N in reach keeps its third (not-ACGT) plane where clean tiles keep the linear window and verifies on the
-// global planes.  After the scan the image is dead: the row keys (ROW_CAP_LDS u64) and motif sizes (u32) lie there.
+// dynamic LDS: [header][R1: image / window][recs][row keys][row motif sizes][all-N stream masks][flag lists, counts][boundary items][cofactors]
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
-constexpr int SMEM_HDR = 192;
+constexpr int SMEM_HDR = 208;
+// header words: 128.. two sets of tile counters used alternately (a set is reset while the other one is still read)
+constexpr int HDR_CNT = 128;       // [parity][4] u32: rows, records, records verified early, long rows
+constexpr int HDR_NEXT = 160;      // {next launch slot, its entry}
+constexpr int HDR_LONG = 168;      // [PRF_LONG_PER_TILE] u64: true ends of the rows whose span is clipped
+constexpr u32 CNT_ROWS = 0, CNT_RECS = 1, CNT_EARLY = 2, CNT_LONG = 3;
 
 // LDS is addressed through explicit address-space pointers everywhere: a generic pointer that the compiler cannot trace back
 // to prf_smem becomes a flat_load, which is slower and waits on both memory counters.
@@ -91,6 +106,10 @@ typedef __attribute__((address_space(3))) prf_u32x4 prf_lds_u4;
 typedef __attribute__((address_space(3))) u64 prf_lds_u64;
 typedef __attribute__((address_space(3))) u32 prf_lds_u32;
 typedef __attribute__((address_space(3))) const u32 prf_lds_cu32;
+typedef __attribute__((address_space(3))) void prf_lds_void;
+typedef __attribute__((address_space(1))) const void prf_glb_cvoid;
+typedef __attribute__((address_space(1))) const u32 prf_glb_cu32;
+typedef __attribute__((address_space(1))) u64 prf_glb_u64;
 
 // Diagnostic build only (make STAMPS=1 -> libprf_stamps.so): per-wave s_memtime stamps at the phase boundaries, written
 // to a debug buffer that nothing else reads.  The product build has no stamp.
@@ -103,39 +122,31 @@ typedef __attribute__((address_space(3))) const u32 prf_lds_cu32;
 #define PRF_STAMP(i) do { } while (0)
 #endif
 
-// what the verification step needs about the tile; lives at the start of LDS (filled by thread 0 while staging)
+// what the verification step needs about the tile; lives at the start of LDS
 struct TileCtx {
     u64 w0;                   // first word of the linear window
     u64 xz_lo, xz_hi;         // positions known to hold no not-ACGT symbol
     const u64 *H, *L, *X;     // linear planes in HBM
     const u64 *const *E;      // device array of the five planes of the symbols outside ACGTN, or nullptr (prf_planes::E)
-    prf_hit_dev *slab;        // this tile's row slab in HBM
-    u64 contig_base;          // a tile lies inside one contig
+    prf_glb_u64 *slab;        // this tile's row slab in HBM (explicitly global: a generic pointer read back from LDS becomes FLAT stores)
     u64 tile_base;            // first position of the tile
-    u32 contig;
     u32 slab_cap;
     u32 min_repeats, min_span;
-    u32 lin_off;              // byte offset of the linear window in LDS
-    u32 has_lin;              // the linear window is staged (clean tiles: from the start; tiles with N in reach: after the scan)
-    u32 xwin_off;             // byte offset of the not-ACGT plane's window (tiles with N in reach, after the scan), else 0
+    u32 lin_off;              // byte offset of R1 (the linear window, once staged) in LDS
+    u32 has_lin;              // the linear window is staged (after the scan)
+    u32 keys_off;             // byte offset of the row list (keys, then motif sizes) in LDS
     u32 cof_off;              // byte offset of the cofactor table in LDS
-    u32 hotw_off;             // byte offset of the exact tasks' stream words in LDS: [exact task][lane], then (k | M << 16) per task
+    u32 hotw_off;             // byte offset of the exact tasks' flag lists in LDS, the counts behind them
     u32 n_exact;              // exact tasks of the plan: motif sizes k_exact0 .. k_exact0 + n_exact - 1, task index = k - k_exact0
     u32 k_exact0;
+    u32 cnt_off;              // byte offset of this tile's counter set in LDS
 };
 static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
-
-__device__ __forceinline__ u32 *smem_row_cnt() { return reinterpret_cast<u32 *>(prf_smem + 160); }          // rows sent to the LDS list
-__device__ __forceinline__ u32 *smem_direct_cnt() { return reinterpret_cast<u32 *>(prf_smem + 164); }       // rows written straight to the slab
-// the row list (lies where the image was): 32-bit sort keys, motif sizes, ends, ROW_CAP_LDS of each
-__device__ __forceinline__ prf_lds_u32 *smem_row_keys() { return (prf_lds_u32 *)(prf_smem + SMEM_HDR); }
-__device__ __forceinline__ prf_lds_u32 *smem_row_ks() { return (prf_lds_u32 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 4); }
-__device__ __forceinline__ prf_lds_u64 *smem_row_ends() { return (prf_lds_u64 *)(prf_smem + SMEM_HDR + ROW_CAP_LDS * 8); }
 
 // cof[k]: the cofactors k/p of the distinct primes p | k, one per byte, largest first (k <= 480 has at most 4
 // distinct primes and k/p <= 240).  The motif seq[a:a+k] is primitive iff it has none of these periods
 // (reference consists_of_perfect_repeats, utils/perfect_repeat_tracker.py:108-142, tries every divisor).
-// Entries 0 .. kmax of the scan are copied to LDS per tile: a table look, not a run-time division, per candidate.
+// Entries 0 .. kmax of the scan are copied to LDS once per workgroup: a table look, not a run-time division, per candidate.
 struct CofTable {
     u32 v[PRF_VMAX_K + 4];
     constexpr CofTable() : v{} {
@@ -152,44 +163,43 @@ struct CofTable {
 };
 __constant__ const CofTable prf_cof_table{};
 
-// One row.  to_lds: into the LDS list that is sorted at the end of the tile.  Sort key: start in the tile (16 bits), then
-// length clipped to 16 bits -- exact, because of the rows that share a start at most one is longer than two motif sizes
-// (two periods on a long common stretch force their gcd, Fine and Wilf).  A full list, or a list that cannot be
-// used yet (a wave emptying its record list in the middle of the scan, while the image still lies there), sends the row
-// straight to the slab, unsorted.
-__device__ __forceinline__ void emit_row(const TileCtx &tc, bool to_lds, u64 a, u64 b, u32 k) {
-    const u64 end = b + k;
-    if (to_lds) {
-        const u32 i = atomicAdd(smem_row_cnt(), 1u);
-        if (i < (u32)ROW_CAP_LDS) {
-            const u64 span = end - a;
-            smem_row_keys()[i] = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
-            smem_row_ks()[i] = k;
-            smem_row_ends()[i] = end;
-            return;
+// One row, as 8 bytes (scan_vertical.h): the first ROW_CAP_LDS of a tile into the LDS list, the others straight to the
+// slab behind them (a tile that dense sorts them in R1 at its end).  Sort key: start in the tile (16 bits), then length
+// clipped to 16 bits -- exact, because of the rows that share a start at most one is longer than two motif sizes (two
+// periods on a long common stretch force their gcd, Fine and Wilf).  The true end of a clipped row goes to
+// the tile's short list of long ends.
+__device__ __forceinline__ void emit_row(const TileCtx &tc, u64 a, u64 b, u32 k) {
+    const u64 span = b + k - a;
+    prf_lds_u32 *cnt = (prf_lds_u32 *)(prf_smem + tc.cnt_off);
+    u32 kv = k;
+    if (span >= 65535ull) {
+        const u32 j = atomicAdd((u32 *)(cnt + CNT_LONG), 1u);
+        if (j < PRF_LONG_PER_TILE) {
+            ((prf_lds_u64 *)(prf_smem + HDR_LONG))[j] = b + k;
+            kv |= (j + 1u) << 16;
         }
     }
-    const u32 j = atomicAdd(smem_direct_cnt(), 1u);
-    if (j < tc.slab_cap) {
-        prf_hit_dev h;
-        h.start = a - tc.contig_base;
-        h.end = end - tc.contig_base;
-        h.k = k;
-        h.contig = tc.contig;
-        tc.slab[j] = h;
+    const u32 key = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
+    const u32 i = atomicAdd((u32 *)(cnt + CNT_ROWS), 1u);
+    if (i < (u32)ROW_CAP_LDS) {
+        prf_lds_u32 *keys = (prf_lds_u32 *)(prf_smem + tc.keys_off);
+        keys[i] = key;
+        keys[ROW_CAP_LDS + i] = kv;
+    } else if (i < tc.slab_cap) {
+        tc.slab[i] = (u64)key | ((u64)kv << 32);
     }
 }
 
 // One 64-position look: mismatch bits (1 = differs, or either side is not ACGT) of positions q .. q+63 against q+k ..,
-// served from the LDS window where it covers both sides, from the global planes elsewhere.  NOT inlined: verification is
-// a few looks per candidate in divergent code, and forty inlined copies of the look were 90 KB of kernel (the
+// served from the LDS window where it covers both sides, from the global planes elsewhere.  NOT inlined: the general
+// routine is a few looks per candidate in divergent code, and forty inlined copies of the look were 90 KB of kernel (the
 // instruction cache is shared by two CUs).
 __device__ __noinline__ u64 tile_mismatch64(u64 q, u32 k) {
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     prf_window_view view;
     view.lds = (prf_lds_cu64 *)(prf_smem + tc.lin_off);
     view.w0 = tc.w0;
-    view.nwords = tc.has_lin ? LW : 0;  // 0: every look goes to the global planes
+    view.nwords = tc.has_lin ? LW : 0;  // 0: every look goes to the global planes (while R1 holds the image)
     view.xz_lo = tc.xz_lo;
     view.xz_hi = tc.xz_hi;
     view.x_in_lds = 0;
@@ -235,7 +245,7 @@ __device__ __forceinline__ bool motif_is_repeat(u64 a, u32 k) {
 //  sc >= 1 (group task, every S = 1 << (sc-1) th aligned group of 8 examined): every examined all-match group of the
 //          stream that is the FIRST examined all-match group of its run; the run is dropped if it starts before the
 //          tile (the previous tile reports it, see boundary_pass).
-__device__ __noinline__ void verify_stream(u64 sp, u32 k, u32 sc, bool to_lds) {
+__device__ __noinline__ void verify_stream(u64 sp, u32 k, u32 sc) {
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
     const long long M = prf_min_matches(k, tc.min_repeats, tc.min_span);
     if (sc == 0) {
@@ -255,7 +265,7 @@ __device__ __noinline__ void verify_stream(u64 sp, u32 k, u32 sc, bool to_lds) {
             const u64 a = sp - 1 + i;
             const u64 after = m >> i;  // bit j = mismatch at a + j, known for j < 64 - i
             const u64 b = after ? a + (u64)__builtin_ctzll(after) : run_end(a + (64 - i), k);
-            if (!motif_is_repeat(a, k)) emit_row(tc, to_lds, a, b, k);
+            if (!motif_is_repeat(a, k)) emit_row(tc, a, b, k);
         }
         return;
     }
@@ -278,13 +288,13 @@ __device__ __noinline__ void verify_stream(u64 sp, u32 k, u32 sc, bool to_lds) {
         const u64 seen = (mm >> look) >> 8;  // bit i = mismatch at p + 8 + i, known for i < 56 - look
         const u64 b = seen ? p + 8 + (u64)__builtin_ctzll(seen) : run_end(p + (64 - look), k);
         if ((long long)(b - a) < M) continue;
-        if (!motif_is_repeat(a, k)) emit_row(tc, to_lds, a, b, k);
+        if (!motif_is_repeat(a, k)) emit_row(tc, a, b, k);
     }
 }
 
-// ---- lean verification for the common case: a candidate of a clean tile whose looks stay inside the LDS window ----
-// Window positions: bit 0 of the window = 64 positions before the tile; the window holds H and L (the not-ACGT plane is known
-// to be zero there).  32-bit words, v_alignbit funnel shifts.
+// ---- lean verification for the common case: a candidate whose looks stay inside the LDS window ----
+// Window positions: bit 0 of the window = WIN_LEAD positions before the tile; the window holds H and L.  The not-ACGT plane is
+// known to be zero there for a clean tile; a mixed tile reads it from global memory (L2), 32 bits at a time like the window.
 constexpr u32 WIN_POS = (u32)LW * 64u;  // positions in the window
 
 __device__ __forceinline__ u32 look32(prf_lds_cu32 *plane, u32 q) {
@@ -296,21 +306,35 @@ __device__ __forceinline__ u64 look64(prf_lds_cu32 *plane, u32 q) {
     const u32 w0 = plane[w], w1 = plane[w + 1], w2 = plane[w + 2];
     return (u64)__builtin_amdgcn_alignbit(w1, w0, sft) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sft) << 32);
 }
+// the same on the global not-ACGT plane: xw = the plane's 32-bit words from window position 0 on (wave-uniform), q per thread
+__device__ __forceinline__ u32 xword(const u32 *xw, u32 w) {
+    return *(prf_glb_cu32 *)(reinterpret_cast<const char *>(xw) + 4u * w);
+}
+__device__ __forceinline__ u32 xlook32(const u32 *xw, u32 q) {
+    const u32 w = q >> 5;
+    return __builtin_amdgcn_alignbit(xword(xw, w + 1), xword(xw, w), q & 31u);
+}
+__device__ __forceinline__ u64 xlook64(const u32 *xw, u32 q) {
+    const u32 w = q >> 5, sft = q & 31u;
+    const u32 w0 = xword(xw, w), w1 = xword(xw, w + 1), w2 = xword(xw, w + 2);
+    return (u64)__builtin_amdgcn_alignbit(w1, w0, sft) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sft) << 32);
+}
 struct WinCtx {
-    prf_lds_cu32 *h, *l, *x, *cof;  // x: the not-ACGT plane's window (tiles with N in reach), nullptr for clean tiles
-    u64 win0;  // global position of window bit 0
+    prf_lds_cu32 *h, *l, *cof;
+    const u32 *xw;  // mixed tile: the not-ACGT plane from window position 0 on (global memory); nullptr for clean tiles
+    u64 win0;       // global position of window bit 0
     u32 min_repeats, min_span;
 };
 
 // mismatch bits of window positions q .. q+31 / q+63 against q+k ..; the caller guarantees q + k + 96 <= WIN_POS
 __device__ __forceinline__ u32 win_mismatch32(const WinCtx &wc, u32 q, u32 k) {
     u32 r = (look32(wc.h, q) ^ look32(wc.h, q + k)) | (look32(wc.l, q) ^ look32(wc.l, q + k));
-    if (wc.x) r |= look32(wc.x, q) | look32(wc.x, q + k);
+    if (wc.xw) r |= xlook32(wc.xw, q) | xlook32(wc.xw, q + k);
     return r;
 }
 __device__ __forceinline__ u64 win_mismatch64(const WinCtx &wc, u32 q, u32 k) {
     u64 r = (look64(wc.h, q) ^ look64(wc.h, q + k)) | (look64(wc.l, q) ^ look64(wc.l, q + k));
-    if (wc.x) r |= look64(wc.x, q) | look64(wc.x, q + k);
+    if (wc.xw) r |= xlook64(wc.xw, q) | xlook64(wc.xw, q + k);
     return r;
 }
 
@@ -359,11 +383,11 @@ __device__ __forceinline__ u32 small_cof(u32 k) {
     return (u32)(t >> (8u * (k & 7u))) & 255u;
 }
 
-// One (stream, exact task) flag of a clean tile: stream (lane rl, bit `bit`), motif size k.  128 positions of both planes
+// One (stream, exact task) flag: stream (lane rl, bit `bit`), motif size k.  128 positions of both planes
 // from the position in front of the stream are read; the mismatch word, the run starts, the run ends and the periods of the
 // primitive-motif test are funnel shifts of those registers.
 __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx &wc, u32 rl, u32 bit, u32 k) {
-    const u32 q = 64u + (bit * 64u + rl) * T;  // window position of the stream's first position
+    const u32 q = WIN_LEAD + (bit * 64u + rl) * T;  // window position of the stream's first position
     const u32 w = (q - 1u) >> 5, sft = (q - 1u) & 31u;
     const u32 a0 = wc.h[w], a1 = wc.h[w + 1], a2 = wc.h[w + 2], a3 = wc.h[w + 3], a4 = wc.h[w + 4];
     const u32 b0 = wc.l[w], b1 = wc.l[w + 1], b2 = wc.l[w + 2], b3 = wc.l[w + 3], b4 = wc.l[w + 4];
@@ -373,8 +397,8 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
     const u64 llo = (u64)__builtin_amdgcn_alignbit(b1, b0, sft) | ((u64)__builtin_amdgcn_alignbit(b2, b1, sft) << 32);
     const u64 lhi = (u64)__builtin_amdgcn_alignbit(b3, b2, sft) | ((u64)__builtin_amdgcn_alignbit(b4, b3, sft) << 32);
     u64 xlo = 0, xhi = 0;
-    if (wc.x) {
-        const u32 c0 = wc.x[w], c1 = wc.x[w + 1], c2 = wc.x[w + 2], c3 = wc.x[w + 3], c4 = wc.x[w + 4];
+    if (wc.xw) {
+        const u32 c0 = xword(wc.xw, w), c1 = xword(wc.xw, w + 1), c2 = xword(wc.xw, w + 2), c3 = xword(wc.xw, w + 3), c4 = xword(wc.xw, w + 4);
         xlo = (u64)__builtin_amdgcn_alignbit(c1, c0, sft) | ((u64)__builtin_amdgcn_alignbit(c2, c1, sft) << 32);
         xhi = (u64)__builtin_amdgcn_alignbit(c3, c2, sft) | ((u64)__builtin_amdgcn_alignbit(c4, c3, sft) << 32);
     }
@@ -405,7 +429,7 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
         const u32 a = q - 1u + i;
         const u64 after = m >> i;  // bit j = mismatch at a + j, known for j < 64 - i
         const u64 b = after ? wc.win0 + a + (u64)__builtin_ctzll(after) : win_run_end(wc, a + (64u - i), k);
-        emit_row(tc, true, wc.win0 + a, b, k);
+        emit_row(tc, wc.win0 + a, b, k);
     }
 }
 
@@ -425,7 +449,7 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
         const u32 gb = 32u + 8u * j;  // bit of the group's first position
         const u64 lead = m << (64u - gb);  // bit 63 = the position directly before the group
         const u32 nb = lead ? (u32)__builtin_clzll(lead) : 64u;  // matches directly before it (>= 32 seen)
-        const bool ok = ((m >> gb) & 0xFFull) == 0 && nb < back && q - 32u + gb - nb >= 64u;
+        const bool ok = ((m >> gb) & 0xFFull) == 0 && nb < back && q - 32u + gb - nb >= WIN_LEAD;
         leaders |= (ok ? 1u : 0u) << j;
         nbs |= (nb & 31u) << (5u * j);
     }
@@ -470,7 +494,7 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
             b = m2 ? wc.win0 + (q + 32u) + (u64)__builtin_ctzll(m2) : win_run_end(wc, q + 96u, k);
         }
         if (b - (wc.win0 + a) < (u64)M) continue;
-        emit_row(tc, true, wc.win0 + a, b, k);
+        emit_row(tc, wc.win0 + a, b, k);
     }
 }
 
@@ -478,58 +502,41 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
 // in the last 8S-1 positions of this tile that group lies in the next tile, whose workgroup drops the run because it does
 // not start there; this tile reports it: per motif size one look at the 32 positions in front of the
 // tile's end.  c = matches directly in front of the end: 1 <= c < 8S <=> such a run exists and starts at end - c.
-__device__ __forceinline__ void boundary_item(const TileCtx &tc, const WinCtx &wc, bool fast, u32 k, u32 S) {
+__device__ __forceinline__ void boundary_item(const TileCtx &tc, const WinCtx &wc, u32 k, u32 S) {
     const u64 tile_end = tc.tile_base + PRF_TILE;
     const u32 back = 8u * S;
-    const u64 mm = fast ? win_mismatch64(wc, 64u + PRF_TILE - 32u, k) : tile_mismatch64(tile_end - 32, k);
+    const u64 mm = win_mismatch64(wc, WIN_LEAD + PRF_TILE - 32u, k);
     const u32 lo = (u32)mm;  // bit i = mismatch at tile_end - 32 + i
     const u32 c = lo ? (u32)__builtin_clz(lo) : 32u;
     if (c == 0 || c >= back) return;
     const u64 a = tile_end - c;
     const u64 hi = mm >> 32;  // bit i = mismatch at tile_end + i
-    const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : (fast ? win_run_end(wc, 64u + PRF_TILE + 32u, k) : run_end(tile_end + 32, k));
+    const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : win_run_end(wc, WIN_LEAD + PRF_TILE + 32u, k);
     if (b - a < (u64)min_matches32(k, tc.min_repeats, tc.min_span)) return;
-    if (!(fast ? win_motif_is_repeat(wc, 64u + PRF_TILE - c, k) : motif_is_repeat(a, k))) emit_row(tc, true, a, b, k);
+    if (!win_motif_is_repeat(wc, WIN_LEAD + PRF_TILE - c, k)) emit_row(tc, a, b, k);
 }
 
-__device__ __forceinline__ prf_lds_u32 *smem_rec_cnt() { return (prf_lds_u32 *)(prf_smem + 128); }   // [MAX_WAVES]: group-task records
+__device__ __forceinline__ prf_lds_u32 *smem_cnt(u32 parity) { return (prf_lds_u32 *)(prf_smem + HDR_CNT) + 4u * parity; }
 
-// A wave emptying its own full list in the middle of the scan: rare, and called from inside the tasks, so not inlined.
-// General routine only; its rows go straight to the slab (the LDS row list lies where the image still is).
-__device__ __noinline__ void flush_records(prf_lds_cu64 *recs, int wave, u32 n, u32 lane) {
-    const u64 tile_base = reinterpret_cast<const TileCtx *>(prf_smem)->tile_base;
-    for (u32 idx = lane; idx < n; idx += 64u) {
-        const u64 rec = recs[(u32)wave * REC_PER_WAVE + idx];
-        const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
-        u32 word = (u32)(rec >> 17);
-        while (word) {
-            const u32 bit = (u32)__builtin_ctz(word);
-            word &= word - 1;
-            verify_stream(tile_base + (u64)(bit * 64u + rl) * T, k, sc, false);
-        }
-    }
-}
-
-// Candidates -> rows, all waves together at the end of the tile.
+// Candidates -> rows, all waves together once the window is staged.
 //  * exact tasks left ballot-compacted lists of (stream, task) flags in LDS: one index space, dealt to the threads from
 //    thread 0 up;
-//  * group-task records are taken by the upper two waves, alternately; the boundary items by the lower half, from its last
-//    thread down.
+//  * group-task records (one list) are taken by the upper two waves, alternately; the boundary items by the lower half, from
+//    its last thread down.
 // Returns the number of (stream, exact task) flags this thread looked at (statistics).
-__device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bitems, u32 n_bitems, u32 tid, u64 *dbg) {
+__device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems, const u32 *xw, u32 tid, u64 *dbg) {
 #ifdef PRF_STAMPS
 #define PRF_VSTAMP(i) do { if (dbg && (tid & 63u) == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PRF_VSTAMP(i) do { } while (0)
 #endif
     const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
-    const bool fast = tc.has_lin != 0;
     WinCtx wc;
     wc.h = (prf_lds_cu32 *)(prf_smem + tc.lin_off);
     wc.l = wc.h + 2 * LW;
-    wc.x = tc.xwin_off ? (prf_lds_cu32 *)(prf_smem + tc.xwin_off) : nullptr;
+    wc.xw = xw;
     wc.cof = (prf_lds_cu32 *)(prf_smem + tc.cof_off);
-    wc.win0 = tc.tile_base - 64;
+    wc.win0 = tc.tile_base - WIN_LEAD;
     wc.min_repeats = tc.min_repeats;
     wc.min_span = tc.min_span;
     // ---- exact tasks: every task left a ballot-compacted list of its flags (lane, stream bit) in LDS (Emit::push_flags).
@@ -559,55 +566,48 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, prf_lds_cu32 *bite
                 first = e >= i ? pre[i] : first;
             });
             const u32 f = lists[e * FLAGS_PER_TASK + (idx - first)], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + e;
-            // (a clean tile's first stream looks at positions in front of the tile, where N is possible and the window
-            // has no not-ACGT plane: general routine)
-            if (fast && ((frl | fbit) || wc.x)) win_verify_flag(tc, wc, frl, fbit, k);
-            else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u, true);
+            // (a clean tile's first stream looks at positions in front of the tile, where N is possible and nothing says so
+            // in the window: general routine)
+            if ((frl | fbit) || xw) win_verify_flag(tc, wc, frl, fbit, k);
+            else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u);
         }
     }
     PRF_VSTAMP(14);
     // ---- group-task records: the upper half of the workgroup, alternating between its two waves (a wave's pass costs the
     // same with 1 or 64 records; the flags keep the lower waves busy meanwhile)
     if (tid >= (u32)NTH / 2u) {
-        prf_lds_u32 *cg = smem_rec_cnt();
-        const u32 c0 = cg[0], c1 = c0 + cg[1], c2 = c1 + cg[2], n = c2 + cg[3];
         const u32 up = (u32)NTH - 1u - tid;  // 0 .. 127: thread 255, 254, ...
-        for (u32 idx = 2u * (up & 63u) + (up >> 6); idx < n; idx += (u32)NTH / 2u) {
-            const u32 slot_idx = idx < c0 ? idx : (idx < c1 ? REC_PER_WAVE + (idx - c0) : (idx < c2 ? 2 * REC_PER_WAVE + (idx - c1) : 3 * REC_PER_WAVE + (idx - c2)));
-            const u64 rec = recs[slot_idx];
+        for (u32 idx = 2u * (up & 63u) + (up >> 6); idx < n_recs; idx += (u32)NTH / 2u) {
+            const u64 rec = recs[idx];
             const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
             u32 word = (u32)(rec >> 17);
             while (word) {
                 const u32 bit = (u32)__builtin_ctz(word);
                 word &= word - 1;
                 const u32 sq = (bit * 64u + rl) * T;
-                if (fast && (sq >= 32u || wc.x)) win_verify_group(tc, wc, 64u + sq, k, 1u << (sc - 1u));
-                else verify_stream(tc.tile_base + sq, k, sc, true);
+                if (sq >= 32u || xw) win_verify_group(tc, wc, WIN_LEAD + sq, k, 1u << (sc - 1u));
+                else verify_stream(tc.tile_base + sq, k, sc);
             }
         }
     } else {
         // ---- boundary items: the lower half, from its last thread down (the flags fill it from the first thread up)
         for (u32 idx = (u32)NTH / 2u - 1u - tid; idx < n_bitems; idx += (u32)NTH / 2u) {
             const u32 it = bitems[idx];
-            boundary_item(tc, wc, fast, it & 0xFFFFu, it >> 16);
+            boundary_item(tc, wc, it & 0xFFFFu, it >> 16);
         }
     }
     return n_flags;
 }
 
-// Group tasks: one 32-bit word per lane (bit b = stream b*64 + lane is flagged for motif size k) -> records of the lanes
-// with a non-zero word.  Every lane of the wave calls this together.
+// The tasks' answers -> LDS lists.  Every lane of the wave calls these together.
 struct Emit {
-    prf_lds_u64 *recs;       // this wave's list in LDS, REC_PER_WAVE records
-    prf_lds_cu64 *all_recs;  // all lists
-    int wave;
+    prf_lds_u64 *recs;       // the tile's record list in LDS, REC_CAP records
+    prf_lds_u32 *cnt;        // this tile's counter set
     int lane;
-    u32 cnt;                 // records in it (wave-uniform)
-    u32 flushed;             // records verified in early flushes (wave-uniform)
 
     // Exact tasks: the lanes' words of ONE task -> the task's list of flags (lane | stream bit << 6), ballot-compacted; the
     // count goes behind the lists.  A task with more flags than its list holds (a tile of long runs) verifies the surplus on
-    // the spot with the general routine (rows straight to the slab, like a flushed record list).
+    // the spot with the general routine.
     __device__ __forceinline__ void push_flags(u32 word, u32 e, u32 k, prf_lds_u32 *hotw, u32 n_exact) {
         typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
         prf_lds_u16 *list = (prf_lds_u16 *)hotw + e * FLAGS_PER_TASK;
@@ -620,27 +620,39 @@ struct Emit {
                 word &= word - 1;
                 const u32 at = n + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
                 if (at < FLAGS_PER_TASK) list[at] = (unsigned short)((u32)lane | (bit << 6));
-                else verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u, false);
+                else verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u);
             }
             n += (u32)__builtin_popcountll(bal);
         }
-        if (lane == 0) hotw[n_exact * 64u + e] = n < FLAGS_PER_TASK ? n : FLAGS_PER_TASK;
+        if (lane == 0) {
+            hotw[n_exact * 64u + e] = n < FLAGS_PER_TASK ? n : FLAGS_PER_TASK;
+            if (n > FLAGS_PER_TASK) atomicAdd((u32 *)(cnt + CNT_EARLY), n - FLAGS_PER_TASK);
+        }
     }
 
+    // Group tasks: one 32-bit word per lane (bit b = stream b*64 + lane is flagged for motif size k) -> one record per lane
+    // with a non-zero word, appended to the tile's list (one LDS atomic per call); a full list -> verified on the spot.
     __device__ __forceinline__ void push_word(u32 word, u32 k, u32 sc) {
         const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
         if (bal == 0) return;
         const u32 n = (u32)__builtin_popcountll(bal);
-        if (cnt + n > (u32)REC_PER_WAVE) {  // wave-uniform: list full -> this wave verifies it now
-            flush_records(all_recs, wave, cnt, (u32)lane);
-            flushed += cnt;
-            cnt = 0;
-        }
+        u32 base = 0;
+        if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd((u32 *)(cnt + CNT_RECS), n);
+        base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(bal));
         if (word) {
-            const u32 idx = cnt + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
-            recs[idx] = make_rec((u32)lane, k, sc, word);
+            const u32 idx = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+            if (idx < (u32)REC_CAP) {
+                recs[idx] = make_rec((u32)lane, k, sc, word);
+            } else {
+                atomicAdd((u32 *)(cnt + CNT_EARLY), 1u);
+                const u64 tile_base = reinterpret_cast<const TileCtx *>(prf_smem)->tile_base;
+                while (word) {
+                    const u32 bit = (u32)__builtin_ctz(word);
+                    word &= word - 1;
+                    verify_stream(tile_base + (u64)(bit * 64u + (u32)lane) * T, k, sc);
+                }
+            }
         }
-        cnt += n;
     }
 };
 
@@ -679,13 +691,13 @@ __device__ __forceinline__ prf_lds_cu4 *slot_after(prf_lds_cu4 *first, int a) {
 
 // ---- group task: motif sizes k0 .. k0+7 (those in `valid`), the 8-row blocks 0 .. 3 of the stream ----
 // S1: every block is examined (stride 1) and a group counts only if the group before it was not all-match; otherwise
-// (stride 2 / 4) every examined all-match group counts.  The per-size words are OR-ed over the blocks and leave as records
-// at the end of the task.
-template <bool HASX, int NC, bool S1>
-__device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, u32 k0, u32 valid, u32 stride, Emit &em) {
+// (stride 2 / 4, and every task of a mixed tile) every examined all-match group counts.  The per-size words are OR-ed over the
+// blocks and leave as records at the end of the task.  The eight sizes are computed as two halves of four, the rows of the
+// second half's last slot loaded in between: 40 row registers instead of 48, four OR chains interleaved.
+template <int NC, bool S1>
+__device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, int lane, u32 k0, u32 valid, u32 stride, u32 allow, Emit &em) {
     constexpr int PS = RG * NC;  // slots per plane
     prf_lds_cu4 *lane_base = vimg + lane;
-    prf_lds_cu4 *xlane_base = ximg + lane;
     u32 prev[8], acc[8];
     static_for<0, 8>([&](auto ic) {
         prev[decltype(ic)::value] = ~0u;  // first group of a stream: counts, verification decides
@@ -693,75 +705,64 @@ __device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg,
     });
 #pragma unroll 1
     for (int tb = 0; tb < 4; tb += (int)stride) {
-        u32 a[3][8];   // rows 8tb .. 8tb+7
-        u32 w[3][16];  // rows 8tb+k0 .. 8tb+k0+15 (k0 % 4 == 0: whole 16-byte slots)
+        u32 a[2][8];   // rows 8tb .. 8tb+7
+        u32 w[2][16];  // rows 8tb+k0 .. 8tb+k0+15 (k0 % 4 == 0: whole 16-byte slots)
         const int g0 = 2 * tb + (int)(k0 >> 2);
         const int wa = g0 & 7;
-        {
-            prf_lds_cu4 *pa = lane_base + 2 * tb * NC;
-            prf_lds_cu4 *pw0 = slot_of<NC>(lane_base, g0);
+        prf_lds_cu4 *pa = lane_base + 2 * tb * NC;
+        prf_lds_cu4 *pw0 = slot_of<NC>(lane_base, g0);
+        static_for<0, 2>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            unpack4(&a[p][0], pa[p * PS]);
+            unpack4(&a[p][4], pa[p * PS + NC]);
+        });
+        auto load_w = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            prf_lds_cu4 *pw = slot_after<NC, g>(pw0, wa);
             static_for<0, 2>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
-                unpack4(&a[p][0], pa[p * PS]);
-                unpack4(&a[p][4], pa[p * PS + NC]);
+                unpack4(&w[p][4 * g], pw[p * PS]);
             });
-            static_for<0, 4>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                prf_lds_cu4 *pw = slot_after<NC, g>(pw0, wa);
-                static_for<0, 2>([&](auto pc) {
-                    constexpr int p = decltype(pc)::value;
-                    unpack4(&w[p][4 * g], pw[p * PS]);
-                });
-            });
-        }
-        if constexpr (HASX) {
-            prf_lds_cu4 *pa = xlane_base + 2 * tb * NC;
-            prf_lds_cu4 *pw0 = slot_of<NC>(xlane_base, g0);
-            unpack4(&a[2][0], pa[0]);
-            unpack4(&a[2][4], pa[NC]);
-            static_for<0, 4>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                unpack4(&w[2][4 * g], slot_after<NC, g>(pw0, wa)[0]);
-            });
-        }
-        // All 8 motif sizes are computed in one straight-line block so that their 8 independent OR chains
-        // interleave (a chain alone is 16 dependent operations); sizes outside `valid` are dropped when records are made.
-        static_for<0, 8>([&](auto kc) {
-            constexpr int kk = decltype(kc)::value;
-            // OR over the 8 rows of (H^H')|(L^L'): 16 operations, no per-row mismatch word
-            u32 o = a[0][0] ^ w[0][kk];
-            o = or_xor(o, a[1][0], w[1][kk]);
-            static_for<1, 8>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                o = or_xor(o, a[0][i], w[0][kk + i]);
-                o = or_xor(o, a[1][i], w[1][kk + i]);
-            });
-            if constexpr (HASX) {
-                static_for<0, 8>([&](auto ic) {
+        };
+        // the four motif sizes 4h .. 4h+3 in one straight-line block: their independent OR chains interleave
+        auto sizes = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            static_for<4 * h, 4 * h + 4>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                // OR over the 8 rows of (H^H')|(L^L'): 16 operations, no per-row mismatch word
+                u32 o = a[0][0] ^ w[0][kk];
+                o = or_xor(o, a[1][0], w[1][kk]);
+                static_for<1, 8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    o = or3(o, a[2][i], w[2][kk + i]);
+                    o = or_xor(o, a[0][i], w[0][kk + i]);
+                    o = or_xor(o, a[1][i], w[1][kk + i]);
                 });
-            }
-            if constexpr (S1) {
-                acc[kk] = bitop3<(TA | (~TB & TC)) & 0xFF>(acc[kk], o, prev[kk]);  // acc | (~o & prev)
-                prev[kk] = o;
-            } else {
-                acc[kk] |= ~o;
-            }
-        });
+                if constexpr (S1) {
+                    acc[kk] = bitop3<(TA | (~TB & TC)) & 0xFF>(acc[kk], o, prev[kk]);  // acc | (~o & prev)
+                    prev[kk] = o;
+                } else {
+                    acc[kk] |= ~o;
+                }
+            });
+        };
+        load_w(std::integral_constant<int, 0>{});
+        load_w(std::integral_constant<int, 1>{});
+        load_w(std::integral_constant<int, 2>{});
+        sizes(std::integral_constant<int, 0>{});
+        load_w(std::integral_constant<int, 3>{});
+        sizes(std::integral_constant<int, 1>{});
     }
     const u32 sc = stride == 1 ? 1u : (stride == 2 ? 2u : 3u);
     static_for<0, 8>([&](auto kc) {
         constexpr int kk = decltype(kc)::value;
-        if ((valid >> kk) & 1u) em.push_word(acc[kk], k0 + (u32)kk, sc);  // wave-uniform condition
+        if ((valid >> kk) & 1u) em.push_word(acc[kk] & allow, k0 + (u32)kk, sc);  // wave-uniform condition
     });
 }
 
-// candidate word of row t: rows t .. t+M-1 all match and row t-1 does not.
+// candidate word of row t: rows t .. t+M-1 all match and row t-1 does not (`before` = mismatch word of row t-1).
 // m is indexed by row+1 (m[0] = the row before the stream), o3[t] = OR of rows t..t+2.
 template <int M, int t, int LM, int LO>
-__device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO]) {
-    const u32 before = m[t];
+__device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO], u32 before) {
     if constexpr (M == 1) return ~m[t + 1] & before;
     else if constexpr (M == 2) return nor_and(m[t + 1], m[t + 2], before);
     else if constexpr (M == 3) return ~o3[t] & before;
@@ -773,23 +774,20 @@ __device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO
 
 // ---- exact task: motif size K whose minimum run length is M < 15; the whole stream in one straight-line block ----
 // Returns the lane's word: bit b set = stream (lane, b) holds a row t in 0..31 that starts a run of >= M matches.
-// Rows 0 .. 31+M-1+K of the extended stream are read ONCE (row i+K is the partner of row i, both in registers).
+// The rows 0 .. 31+M-1+K of the extended stream are read ONCE, slot by slot (4 rows of both planes); a mismatch word is
+// computed as soon as its partner row (K further on) is there, a start word as soon as its M rows are: the compiler sees
+// straight-line code in that order and keeps the live window -- K + 4 rows, M + 1 mismatch words, M - 2 triple ORs -- in
+// registers (round 2 read all 60 rows first: 128 VGPRs, four workgroups per CU).
+// relax (mixed tile): a stream whose first M rows all match counts as well -- together with the starts that is "some M
+// matching rows begin in this stream", which no added match (a not-ACGT position reads as A) can take away.
 // Not inlined: one compact function per (K, M), called by the one wave that runs the task.
 template <int K, int M, int NC>
-__device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx) {
+__device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lane, bool relax) {
     constexpr int PS = RG * NC;
     constexpr int NM = T + M - 1;            // mismatch words of rows 0 .. NM-1
     constexpr int NG = (NM + K + 3) / 4;     // 16-byte slots of rows read
     static_assert(4 * NG <= 2 * T, "an exact task reads its own lane and the next one");
     prf_lds_cu4 *lane_base = vimg + lane;
-    u32 r0[4 * NG], r1[4 * NG];
-    static_for<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
-        const prf_u32x4 v0 = ps[0], v1 = ps[PS];
-        r0[4 * g] = v0.x; r0[4 * g + 1] = v0.y; r0[4 * g + 2] = v0.z; r0[4 * g + 3] = v0.w;
-        r1[4 * g] = v1.x; r1[4 * g + 1] = v1.y; r1[4 * g + 2] = v1.z; r1[4 * g + 3] = v1.w;
-    });
     // Row -1 of stream (lane, b) is row T-1 of stream (lane-1, b); for lane 0 it is row T-1 of stream (63, b-1):
     // lane 63's word one bit up, with bit 0 (the previous tile's last stream) unknown -> "mismatch", verification decides.
     const int pl = (lane + 63) & 63;
@@ -799,41 +797,30 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, prf_lds
         p0 <<= 1;
         p1 <<= 1;
     }
+    u32 r0[4 * NG], r1[4 * NG];
     u32 m[NM + 1];
-    m[0] = or_xor(p0 ^ r0[K - 1], p1, r1[K - 1]);
-    static_for<0, NM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        m[i + 1] = or_xor(r0[i] ^ r0[i + K], r1[i], r1[i + K]);
-    });
-    if (hasx) {  // wave-uniform: tile with not-ACGT positions in reach
-        prf_lds_cu4 *xlane_base = ximg + lane;
-        u32 rx[4 * NG];
-        static_for<0, NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const prf_u32x4 v = slot_of<NC>(xlane_base, g)[0];
-            rx[4 * g] = v.x; rx[4 * g + 1] = v.y; rx[4 * g + 2] = v.z; rx[4 * g + 3] = v.w;
-        });
-        u32 px = (ximg + pl + (RG - 1) * NC)[0].w;
-        if (lane == 0) px <<= 1;
-        m[0] = or3(m[0], px, rx[K - 1]);
-        static_for<0, NM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            m[i + 1] = or3(m[i + 1], rx[i], rx[i + K]);
-        });
-    }
-    if (lane == 0) m[0] |= 1u;
     u32 o3[NM];
-    if constexpr (M >= 3) {
-        static_for<0, NM - 2>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            o3[i] = or3(m[i + 1], m[i + 2], m[i + 3]);
-        });
-    }
     u32 hot = 0;
-    static_for<0, T / 2>([&](auto tc) {
-        constexpr int t = 2 * decltype(tc)::value;
-        hot = or3(hot, start_word<M, t>(m, o3), start_word<M, t + 1>(m, o3));
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
+        const prf_u32x4 v0 = ps[0], v1 = ps[PS];
+        r0[4 * g] = v0.x; r0[4 * g + 1] = v0.y; r0[4 * g + 2] = v0.z; r0[4 * g + 3] = v0.w;
+        r1[4 * g] = v1.x; r1[4 * g + 1] = v1.y; r1[4 * g + 2] = v1.z; r1[4 * g + 3] = v1.w;
+        static_for<0, 4>([&](auto jc) {
+            constexpr int i = 4 * g + decltype(jc)::value - K;  // the mismatch row whose partner row has just arrived
+            if constexpr (i == -1) {
+                m[0] = or_xor(p0 ^ r0[K - 1], p1, r1[K - 1]);
+                if (lane == 0) m[0] |= 1u;
+            } else if constexpr (i >= 0 && i < NM) {
+                m[i + 1] = or_xor(r0[i] ^ r0[i + K], r1[i], r1[i + K]);
+                if constexpr (M >= 3 && i >= 2) o3[i - 2] = or3(m[i - 1], m[i], m[i + 1]);
+                constexpr int t = i - (M - 1);  // the start word whose last row this is
+                if constexpr (t >= 0 && t < T) hot |= start_word<M, t>(m, o3, m[t]);
+            }
+        });
     });
+    if (relax) hot |= start_word<M, 0>(m, o3, ~0u);
     return hot;
 }
 
@@ -847,27 +834,28 @@ constexpr int exact_variant_k(int v) {
     return K;
 }
 template <int LO, int HI, int NC>
-__device__ __forceinline__ u32 exact_dispatch(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx, u32 v) {
+__device__ __forceinline__ u32 exact_dispatch(prf_lds_cu4 *vimg, int lane, bool relax, u32 v) {
     if constexpr (LO == HI) {
         constexpr int K = exact_variant_k(LO), M = K + (LO - exact_variant_of(K, K));
         static_assert(M >= K && M < SMALL_M && exact_variant_of(K, M) == LO, "variant numbering");
-        return exact_stream<K, M, NC>(vimg, ximg, lane, hasx);
+        return exact_stream<K, M, NC>(vimg, lane, relax);
     } else {
         constexpr int MID = (LO + HI) / 2;
-        if (v <= (u32)MID) return exact_dispatch<LO, MID, NC>(vimg, ximg, lane, hasx, v);  // wave-uniform
-        return exact_dispatch<MID + 1, HI, NC>(vimg, ximg, lane, hasx, v);
+        if (v <= (u32)MID) return exact_dispatch<LO, MID, NC>(vimg, lane, relax, v);  // wave-uniform
+        return exact_dispatch<MID + 1, HI, NC>(vimg, lane, relax, v);
     }
 }
 
 template <int NC>
-__device__ __forceinline__ u32 exact_any(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, int lane, bool hasx, u32 k, u32 M) {
+__device__ __forceinline__ u32 exact_any(prf_lds_cu4 *vimg, int lane, bool relax, u32 k, u32 M) {
     // (min_repeats - 1) * k <= M < SMALL_M and min_repeats >= 2: k <= M
     const u32 v = (k - 1u) * (2u * (u32)SMALL_M - k) / 2u + (M - k);
-    return exact_dispatch<0, exact_variants() - 1, NC>(vimg, ximg, lane, hasx, v);
+    return exact_dispatch<0, exact_variants() - 1, NC>(vimg, lane, relax, v);
 }
 
-template <bool HASX, int NC>
-__device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, prf_lds_u32 *hotw, const prf_vplan &plan, int wave, int lane,
+// relax: mixed tile (see the head of the file); allow = ~(streams of this lane that hold nothing but N), all ones on a clean tile
+template <int NC>
+__device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, const prf_vplan &plan, int wave, int lane, bool relax, u32 allow,
                                           Emit &em, u64 *dbg) {
     const u32 t_end = plan.wave_begin[wave + 1];
 #ifdef PRF_STAMPS
@@ -879,17 +867,17 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_cu4 *ximg, 
         if (dbg && lane == 0 && ti - plan.wave_begin[wave] < 8u) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
 #endif
         if (task.kind == 0) {
-            if (task.stride == 1) group_task<HASX, NC, true>(vimg, ximg, lane, task.k0, task.valid, 1u, em);
-            else group_task<HASX, NC, false>(vimg, ximg, lane, task.k0, task.valid, task.stride, em);
+            if (task.stride == 1 && !relax) group_task<NC, true>(vimg, lane, task.k0, task.valid, 1u, allow, em);
+            else group_task<NC, false>(vimg, lane, task.k0, task.valid, task.stride, allow, em);
         } else {
 #ifdef PRF_STAMPS
             const u64 tc0 = __builtin_amdgcn_s_memtime();
-            const u32 word = exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind);
+            const u32 word = exact_any<NC>(vimg, lane, relax, task.k0, task.kind);
             asm volatile("" ::"v"(word));
             t_call += __builtin_amdgcn_s_memtime() - tc0;
-            em.push_flags(word, task.item0, task.k0, hotw, plan.n_exact);
+            em.push_flags(word & allow, task.item0, task.k0, hotw, plan.n_exact);
 #else
-            em.push_flags(exact_any<NC>(vimg, ximg, lane, HASX, task.k0, task.kind), task.item0, task.k0, hotw, plan.n_exact);
+            em.push_flags(exact_any<NC>(vimg, lane, relax, task.k0, task.kind) & allow, task.item0, task.k0, hotw, plan.n_exact);
 #endif
         }
     }
@@ -905,164 +893,96 @@ __device__ __forceinline__ void set_prio(u32 p) {  // (s_setprio takes an immedi
     else __builtin_amdgcn_s_setprio(3);
 }
 
-// Grid: persistent workgroups, 4 per CU (or one per entry of the launch list if that is fewer): workgroup b takes the launch
-// slots b, b + gridDim, ...  (tiles in position order; slabs and counts are indexed by slot, so the order of execution does
-// not show in the output).  The global loads of the NEXT tile's staging data are issued at the start of the rows phase of
-// the current one and land in registers while the rows are sorted: the memory round trip in front of every tile (5-8 k
-// cycles of a 45 k-cycle tile, every wave waiting) is off the critical path, and the per-workgroup set-up (boundary items,
-// cofactor table, the constant part of the tile context) is paid once per workgroup instead of once per tile.
-// __launch_bounds__(256, 4): 128 VGPRs; with NC = 72 the 39.6 KB of LDS allow 4 workgroups per CU.
-template <int NC>
-struct StageRegs {
-    static constexpr int extra = NC - 64;
-    static constexpr int NLF = (2 * LW) / NTH;        // full rounds of linear words
-    static constexpr int NLT = (2 * LW) - NLF * NTH;  // tail
-    // virtual-lane slots: (plane, row group, first lanes again).  3 planes x 8 row groups x 16 extra lanes (NC = 80,
-    // tile with N in reach) are 384 slots: two rounds of the 256 threads cover every instantiated width.
-    static constexpr int NXR = (3 * RG * extra + NTH - 1) / NTH;
-    static_assert(3 * RG * extra <= NXR * NTH, "virtual-lane staging rounds do not cover the image width");
-    static_assert(NLF >= 4, "the not-ACGT plane of a tile with N in reach travels in the window's registers");
-    static_assert(NLF % 2 == 0, "linear words travel as pairs");
-    prf_u32x4 vh0, vh1, vl0, vl1;
-    // clean tile: the linear window, two 64-bit words per vector; tile with N in reach: q[0], q[1] = its two X-plane slots.
-    // (One set of registers for both, written by loads only -- no conversion, which would wait for the data -- and the
-    // two kinds of tile are separate branches from the first load to the last: a shared prefix made the compiler wait for
-    // the image loads before it issued the window loads.)
-    prf_u32x4 q[NLF / 2];
-    u64 lt;
-    prf_u32x4 ev[NXR], en[NXR];
-    uint4 info;
-    u32 entry;    // the launch-list entry these registers belong to
+__device__ __forceinline__ u32 lds_add(prf_lds_u32 *p, u32 v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-    // All global loads of a thread are issued back to back, nothing waits for them here.  Every address is a wave-uniform
-    // base (scalar registers) plus a 32-bit per-thread offset: per-thread 64-bit pointers would be hoisted out of the tile
-    // loop and spilled.
+// 16 bytes per lane, global memory -> LDS without a register in between (LDS-DMA): lane l's 16 bytes land at lds + 16 l
+__device__ __forceinline__ void dma16(const void *src_lane, u32 lds_byte_off) {
+    __builtin_amdgcn_global_load_lds((prf_glb_cvoid *)src_lane, (prf_lds_void *)(prf_smem + lds_byte_off), 16, 0, 0);
+}
+
+// Grid: persistent workgroups, as many as are resident at once (or one per entry of the launch list if that is fewer):
+// workgroup b takes the launch slots b, then tickets of its XCD (tiles in position order; slabs and counts are indexed by
+// slot, so the order of execution does not show in the output).
+// What a tile needs from HBM arrives without waiting threads: the NEXT tile's bit-sliced image is sent to R1 by LDS-DMA
+// when this tile's candidates are verified (R1 is dead then) and lands while the rows are sorted; the two slots per thread
+// that become the virtual lanes 64.. are ordinary loads issued at the same point and held in 8 registers.  The window of the
+// linear planes follows the scan by DMA: that wait is exposed to this workgroup and covered by the five others on the CU.
+template <int NC>
+struct NextRegs {
+    static constexpr int extra = NC - 64;
+    static constexpr u32 n_extra = (u32)(2 * RG * extra);  // virtual-lane slots of a tile: (plane, row group, first lanes again)
+    static_assert(n_extra <= (u32)NTH, "one virtual-lane slot per thread");
+    static_assert((RG * extra) % 64 == 0, "virtual-lane staging: one plane per wave");
+    prf_u32x4 ev, en;
+    u32 entry;  // the launch-list entry these registers belong to
+
     __device__ __forceinline__ static prf_u32x4 ld16(const void *ubase, u32 byte_off) {
         return *reinterpret_cast<const prf_u32x4 *>(reinterpret_cast<const char *>(ubase) + byte_off);
     }
-    __device__ __forceinline__ static u64 ld8(const void *ubase, u32 byte_off) {
-        return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ubase) + byte_off);
-    }
-    __device__ __forceinline__ void load(const prf_vscan_args &g, u32 e, int tid) {
+    // Every address is a wave-uniform base (scalar registers) plus a 32-bit per-thread offset.
+    __device__ __forceinline__ void load(const prf_vscan_args &g, u32 e, int tid, int wave, u32 r1_off) {
         e = (u32)__builtin_amdgcn_readfirstlane((int)e);
         entry = e;
-        const bool hasx = (e & PRF_LAUNCH_MIXED) != 0;
         const u64 tile = e & ~PRF_LAUNCH_MIXED;
-        const prf_u32x4 *ph = reinterpret_cast<const prf_u32x4 *>(g.VH) + tile * (RG * 64), *pL = reinterpret_cast<const prf_u32x4 *>(g.VL) + tile * (RG * 64),
-                        *px = reinterpret_cast<const prf_u32x4 *>(g.VX) + tile * (RG * 64);
-        const int np = hasx ? 3 : 2;
-        // slot (rg + 4*j, l) of a plane, rg = tid >> 6, l = tid & 63: slot index tid + 256 j
+        const prf_u32x4 *ph = reinterpret_cast<const prf_u32x4 *>(g.VH) + tile * (RG * 64), *pL = reinterpret_cast<const prf_u32x4 *>(g.VL) + tile * (RG * 64);
         u32 ut = (u32)tid;
-        asm volatile("" : "+v"(ut));  // (opaque: keeps the address arithmetic inside the loop, see above)
-        const u32 o16 = ut * 16u, o8 = ut * 8u;
-        lt = 0;
-        if (hasx) {
-            vh0 = ld16(ph, o16); vh1 = ld16(ph, o16 + 4u * 64u * 16u); vl0 = ld16(pL, o16); vl1 = ld16(pL, o16 + 4u * 64u * 16u);
-            q[0] = ld16(px, o16);
-            q[1] = ld16(px, o16 + 4u * 64u * 16u);
-            static_for<2, NLF / 2>([&](auto ic) { q[decltype(ic)::value] = prf_u32x4{0, 0, 0, 0}; });
-        } else {
-            vh0 = ld16(ph, o16); vh1 = ld16(ph, o16 + 4u * 64u * 16u); vl0 = ld16(pL, o16); vl1 = ld16(pL, o16 + 4u * 64u * 16u);
-            // the planes have readable padding in front
-            const u64 *wh = g.H + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE), *wl = g.L + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE - LW);
-            static_for<0, NLF>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const u32 idx = ut + (u32)(i * NTH);  // one round straddles H -> L
-                const u32 ob = o8 + (u32)(i * NTH * 8);
-                u64 w;
-                if constexpr ((i + 1) * NTH <= LW) w = ld8(wh, ob);
-                else if constexpr (i * NTH >= LW) w = ld8(wl, ob);
-                else w = idx < (u32)LW ? ld8(wh, ob) : ld8(wl, ob);
-                if constexpr (i % 2 == 0) { q[i / 2].x = (u32)w; q[i / 2].y = (u32)(w >> 32); }
-                else { q[i / 2].z = (u32)w; q[i / 2].w = (u32)(w >> 32); }
+        asm volatile("" : "+v"(ut));  // (opaque: keeps the address arithmetic inside the loop)
+        // the image: 2 planes x 8 row groups of 1 KiB, four pieces per wave; piece (p, rg) -> slots [(p RG + rg) NC, + 64)
+        {
+            const u32 p = (u32)wave >> 1, rg0 = ((u32)wave & 1u) * 4u;
+            const prf_u32x4 *pp = p ? pL : ph;
+            const u32 l16 = (ut & 63u) * 16u;
+            static_for<0, 4>([&](auto ic) {
+                constexpr u32 i = (u32)decltype(ic)::value;
+                dma16(reinterpret_cast<const char *>(pp) + ((rg0 + i) * 64u * 16u + l16), r1_off + ((p * RG + rg0 + i) * (u32)NC) * 16u);
             });
-            if (tid < NLT) lt = ld8(wl, o8 + (u32)(NLF * NTH * 8));
         }
-        const u32 n_extra = (u32)(np * RG * extra);
-        static_for<0, NXR>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const u32 sx = ut + (u32)(r * NTH);
-            ev[r] = prf_u32x4{0, 0, 0, 0};
-            en[r] = ev[r];
-            if (sx < n_extra) {
-                // the plane is the same for a whole wave (RG * extra is a multiple of 64): a scalar select of the base
-                static_assert((RG * extra) % 64 == 0, "virtual-lane staging: one plane per wave");
-                const u32 pw = (u32)__builtin_amdgcn_readfirstlane((int)(sx / (u32)(RG * extra)));
-                const u32 erg = (sx / (u32)extra) % (u32)RG, el = sx % (u32)extra;
-                const u32 i0 = (erg * 64u + el) * 16u, i1 = i0 + (u32)(RG * 64) * 16u;  // the same slot of the next tile
-                if (pw == 0) {  // (three branches, not a selected pointer: the compiler makes a table in scratch memory of that)
-                    ev[r] = ld16(ph, i0);
-                    en[r] = ld16(ph, i1);
-                } else if (pw == 1) {
-                    ev[r] = ld16(pL, i0);
-                    en[r] = ld16(pL, i1);
-                } else {
-                    ev[r] = ld16(px, i0);
-                    en[r] = ld16(px, i1);
-                }
+        const prf_u32x4 z = {0, 0, 0, 0};
+        ev = z;
+        en = z;
+        if (ut < n_extra) {
+            const u32 pw = (u32)__builtin_amdgcn_readfirstlane((int)(ut / (u32)(RG * extra)));
+            const u32 erg = (ut / (u32)extra) % (u32)RG, el = ut % (u32)extra;
+            const u32 i0 = (erg * 64u + el) * 16u, i1 = i0 + (u32)(RG * 64) * 16u;  // the same slot of the next tile
+            if (pw == 0) {
+                ev = ld16(ph, i0);
+                en = ld16(ph, i1);
+            } else {
+                ev = ld16(pL, i0);
+                en = ld16(pL, i1);
             }
-        });
-        // the tile's contig (contigs start on tile boundaries, so every run that starts in this tile lies in it): one load
-        info = make_uint4(0, 0, 0, 0);
-        if (tid == 0) info = g.tile_info[tile];
+        }
     }
-
     __device__ __forceinline__ void clear() {
         const prf_u32x4 z = {0, 0, 0, 0};
-        vh0 = vh1 = vl0 = vl1 = z;
-        static_for<0, NLF / 2>([&](auto ic) { q[decltype(ic)::value] = z; });
-        lt = 0;
-        static_for<0, NXR>([&](auto rc) { ev[decltype(rc)::value] = en[decltype(rc)::value] = z; });
-        info = make_uint4(0, 0, 0, 0);
+        ev = en = z;
         entry = 0;
     }
-
-    // registers -> the LDS image, the linear window (clean tile) or the not-ACGT plane in its place (tile with N in reach)
-    __device__ __forceinline__ void store(prf_lds_u4 *vimg, prf_lds_u4 *ximg, prf_lds_u64 *lin, int tid) const {
-        constexpr int nc = NC;
-        const bool hasx = (entry & PRF_LAUNCH_MIXED) != 0;
-        const int np = hasx ? 3 : 2;
-        const int rg = tid >> 6, l = tid & 63;
-        vimg[(0 * RG + rg) * nc + l] = vh0;
-        vimg[(0 * RG + rg + 4) * nc + l] = vh1;
-        vimg[(1 * RG + rg) * nc + l] = vl0;
-        vimg[(1 * RG + rg + 4) * nc + l] = vl1;
-        if (hasx) {
-            ximg[rg * nc + l] = q[0];
-            ximg[(rg + 4) * nc + l] = q[1];
-        } else {
-            static_for<0, NLF>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                lin[tid + i * NTH] = i % 2 == 0 ? ((u64)q[i / 2].x | ((u64)q[i / 2].y << 32)) : ((u64)q[i / 2].z | ((u64)q[i / 2].w << 32));
-            });
-            if (tid < NLT) lin[NLF * NTH + tid] = lt;
+    // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
+    __device__ __forceinline__ void store(prf_lds_u4 *vimg, int tid) const {
+        const u32 sx = (u32)tid;
+        if (sx < n_extra) {
+            const u32 p = sx / (u32)(RG * extra), erg = (sx / (u32)extra) % (u32)RG, el = sx % (u32)extra;
+            vimg[p * RG * NC + erg * (u32)NC + 64u + el] = (ev >> 1) | (en << 31);
         }
-        const u32 n_extra = (u32)(np * RG * extra);
-        static_for<0, NXR>([&](auto rc) {  // virtual lanes 64..: the first lanes again, one bit up, bit 31 from the next tile
-            constexpr int r = decltype(rc)::value;
-            const u32 sx = (u32)tid + (u32)(r * NTH);
-            if (sx < n_extra) {
-                const u32 p = sx / (u32)(RG * extra), erg = (sx / (u32)extra) % (u32)RG, el = sx % (u32)extra;
-                const prf_u32x4 v = (ev[r] >> 1) | (en[r] << 31);
-                const u32 dst = erg * (u32)nc + 64u + el;
-                if (p == 2) ximg[dst] = v;
-                else vimg[p * RG * nc + dst] = v;
-            }
-        });
     }
 };
 
 template <int NC>
-__global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
-    constexpr int nc = NC;
-    prf_lds_u4 *vimg = (prf_lds_u4 *)(prf_smem + SMEM_HDR);
-    constexpr u32 lin_off = (u32)SMEM_HDR + (u32)((size_t)2 * RG * nc * sizeof(prf_u32x4));
-    prf_lds_u64 *lin = (prf_lds_u64 *)(prf_smem + lin_off);
-    prf_lds_u4 *ximg = (prf_lds_u4 *)(prf_smem + lin_off);  // tiles with N in reach: instead of the window
-    prf_lds_u64 *recs = lin + 2 * LW;
-    prf_lds_u32 *hotw = (prf_lds_u32 *)(recs + MAX_WAVES * REC_PER_WAVE);  // exact tasks: [task][lane] stream words, then 16 x (k | M << 16)
-    prf_lds_u32 *bitems = hotw + g.plan.n_exact * 64u + 16u;                // boundary items, plan.n_group_k of them
-    prf_lds_u32 *hdr_cnt = (prf_lds_u32 *)(prf_smem + 128);
+__global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
+    constexpr u32 R1_OFF = (u32)SMEM_HDR, R1_BYTES = (u32)(2 * RG * NC * 16);
+    constexpr u32 RECS_OFF = R1_OFF + R1_BYTES, KEYS_OFF = RECS_OFF + (u32)REC_CAP * 8u, ALLOW_OFF = KEYS_OFF + 2u * (u32)ROW_CAP_LDS * 4u,
+                  HOTW_OFF = ALLOW_OFF + 256u;
+    static_assert(2 * LW * 8 <= (int)R1_BYTES, "the window of the linear planes must fit the image's region");
+    static_assert((2 * LW / 2 + 63) / 64 <= 5 * MAX_WAVES, "window pieces per wave");
+    prf_lds_u4 *vimg = (prf_lds_u4 *)(prf_smem + R1_OFF);
+    prf_lds_u64 *recs = (prf_lds_u64 *)(prf_smem + RECS_OFF);
+    prf_lds_u32 *keys = (prf_lds_u32 *)(prf_smem + KEYS_OFF);
+    prf_lds_u32 *nostart = (prf_lds_u32 *)(prf_smem + ALLOW_OFF);
+    prf_lds_u32 *hotw = (prf_lds_u32 *)(prf_smem + HOTW_OFF);  // exact tasks: flag lists (256 B per task), then 16 counts
+    prf_lds_u32 *bitems = hotw + g.plan.n_exact * 64u + 16u;    // boundary items, plan.n_group_k of them
 
     const int tid0 = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -1072,8 +992,8 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
 
     // ---- once per workgroup ----
     set_prio(g.plan.prio & 3u);
-    StageRegs<NC> sr;
-    sr.load(g, entry_of(blockIdx.x), tid0);
+    NextRegs<NC> sr;
+    sr.load(g, entry_of(blockIdx.x), tid0, wave, R1_OFF);
     // boundary items: (motif size, examined-group stride) of every motif size a group task scans
     for (u32 v = (u32)tid0; v < 8u * g.plan.n_tasks; v += (u32)NTH) {
         const prf_vtask task = g.plan.tasks[v >> 3];
@@ -1085,7 +1005,6 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         prf_lds_u32 *cof_lds = bitems + g.plan.n_group_k;
         for (int i = tid0; i < (int)g.plan.cof_words; i += NTH) cof_lds[i] = prf_cof_table.v[i];
     }
-
     if (tid0 == 0) {  // the constant part of the tile context
         TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
         tcw->H = g.H; tcw->L = g.L; tcw->X = g.X;
@@ -1093,11 +1012,12 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
         tcw->slab_cap = g.slab_cap;
         tcw->min_repeats = g.min_repeats;
         tcw->min_span = g.min_span;
-        tcw->lin_off = lin_off;
-        tcw->hotw_off = lin_off + (u32)(2 * LW * sizeof(u64) + MAX_WAVES * REC_PER_WAVE * sizeof(u64));
+        tcw->lin_off = R1_OFF;
+        tcw->keys_off = KEYS_OFF;
+        tcw->hotw_off = HOTW_OFF;
         tcw->n_exact = g.plan.n_exact;
         tcw->k_exact0 = g.plan.k_exact0;
-        tcw->cof_off = tcw->hotw_off + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
+        tcw->cof_off = HOTW_OFF + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
     }
 
     // Launch slots are handed out dynamically (tiles differ in cost by a factor of three; a fixed stride leaves the last
@@ -1107,9 +1027,10 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const u32 xcd = blockIdx.x & 7u;
     const u32 first_ticket = (gridDim.x - xcd + 7u) >> 3;  // workgroups of this XCD = slots taken without a ticket
     u64 *ticket_word = g.counters + (PRF_CNT_SHARD0 + xcd * PRF_CNT_SHARD_STRIDE + PRF_SH_TILE_TICKET);
-    prf_lds_u32 *next_words = (prf_lds_u32 *)(prf_smem + 176);  // {next slot, its launch-list entry}
+    prf_lds_u32 *next_words = (prf_lds_u32 *)(prf_smem + HDR_NEXT);  // {next slot, its launch-list entry}
     u32 slot_next = 0;
-    for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next) {
+    u32 parity = 0;
+    for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next, parity ^= 1u) {
     // (opaque per round: what derives from the thread index is recomputed, not carried through the scan's calls in
     // registers that would have to be spilled)
     int tid = tid0;
@@ -1118,34 +1039,41 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     const u32 entry = sr.entry;
     const bool hasx = (entry & PRF_LAUNCH_MIXED) != 0;
     const u64 tile = entry & ~PRF_LAUNCH_MIXED;
+    prf_lds_u32 *cnt = smem_cnt(parity);
 
     PRF_STAMP(0);
 #ifdef PRF_STAMPS
     if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
-    // ---- 1. stage: the registers loaded during the previous tile's rows phase (or above) -> LDS ----
+    // ---- 1. stage: the image is in R1 (DMA issued during the previous tile's rows phase, or above); the virtual lanes from
+    // the two prefetched slots; a mixed tile's mask of the streams that hold nothing but N ----
     set_prio(g.plan.prio & 3u);
     {
-        sr.store(vimg, ximg, lin, tid);
-        if (tid < 2 * MAX_WAVES + 3) hdr_cnt[tid] = 0;  // list lengths, row count, direct-row count, flushed records
+        sr.store(vimg, tid);
+        if (hasx && tid < 64) {  // AND of the 32 rows of the not-ACGT plane: bit b = stream (b, lane) is all N
+            const prf_u32x4 *px = reinterpret_cast<const prf_u32x4 *>(g.VX) + tile * (RG * 64);
+            prf_u32x4 v[RG];
+            static_for<0, RG>([&](auto rc) { v[decltype(rc)::value] = NextRegs<NC>::ld16(px, ((u32)decltype(rc)::value * 64u + (u32)tid) * 16u); });
+            prf_u32x4 a = v[0];
+            static_for<1, RG>([&](auto rc) { a &= v[decltype(rc)::value]; });
+            nostart[tid] = a.x & a.y & a.z & a.w;
+        }
+        if (tid < 4) cnt[tid] = 0;  // rows, records, early verifications, long rows (the other set is still read by slow waves)
         if (tid == 0) {  // the tile's part of the context (the rest was written once, above)
             TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
             tcw->w0 = tile * PRF_TILE_WORDS - LIN_PRE;
             tcw->xz_lo = hasx ? 0 : tile * PRF_TILE;  // a clean tile and its successor hold no not-ACGT position
             tcw->xz_hi = hasx ? 0 : (tile + 2) * PRF_TILE;
-            tcw->slab = g.slabs + (u64)slot * g.slab_cap;
-            tcw->contig = sr.info.x;
-            tcw->contig_base = (u64)sr.info.z | ((u64)sr.info.w << 32);
+            tcw->slab = (prf_glb_u64 *)(g.slabs + (u64)slot * g.slab_cap);
             tcw->tile_base = tile * PRF_TILE;
-            tcw->has_lin = hasx ? 0u : 1u;
-            tcw->xwin_off = 0u;
+            tcw->has_lin = 0u;
+            tcw->cnt_off = (u32)HDR_CNT + 16u * parity;
         }
     }
     PRF_STAMP(1);
-    __syncthreads();
+    __syncthreads();  // (waits for the image's DMA too)
     PRF_STAMP(2);
-    // the ticket for the tile after this one: drawn here, behind the wait for the staging loads (an atomic in front of it
-    // would be waited for with them: 4 k cycles), used before the last barrier of the tile.  The compiler turns the
+    // the ticket for the tile after this one: drawn here, used before the last barrier of the tile.  The compiler turns the
     // returning atomic into a wave-aggregated one and waits for its value on the spot: the plan deals it to the wave
     // with the least other work.
     u64 ticket = 0;
@@ -1153,199 +1081,201 @@ __global__ __launch_bounds__(NTH, 4) void prf_vscan_kernel(prf_vscan_args g) {
     if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
 
     // ---- 2. scan ----
-    // Issue priority (plan.prio): each SIMD hosts waves of four workgroups in different phases, about a third busy; the
-    // phases that are chains of dependent LDS round trips go first, the scan takes the slots that are left.
     set_prio(((g.plan.slack_waves >> wave) & 1u) ? (g.plan.prio >> 4) & 3u : (g.plan.prio >> 2) & 3u);
     Emit em;
-    em.recs = recs + wave * REC_PER_WAVE;
-    em.all_recs = (prf_lds_cu64 *)recs;
-    em.wave = wave;
+    em.recs = recs;
+    em.cnt = cnt;
     em.lane = lane;
-    em.cnt = 0;
-    em.flushed = 0;
 #ifdef PRF_STAMPS
     u64 *task_dbg = g.dbg ? g.dbg + ((u64)slot * MAX_WAVES + wave) * 16 : nullptr;
 #else
     u64 *task_dbg = nullptr;
 #endif
-    if (hasx) run_tasks<true, NC>((prf_lds_cu4 *)vimg, (prf_lds_cu4 *)ximg, hotw, g.plan, wave, lane, em, task_dbg);
-    else run_tasks<false, NC>((prf_lds_cu4 *)vimg, (prf_lds_cu4 *)ximg, hotw, g.plan, wave, lane, em, task_dbg);
-    if (lane == 0) {
-        hdr_cnt[wave] = em.cnt;
-        if (em.flushed) atomicAdd((u32 *)(prf_smem + 168), em.flushed);
+    {
+        const u32 allow = hasx ? ~nostart[lane] : ~0u;
+        run_tasks<NC>((prf_lds_cu4 *)vimg, hotw, g.plan, wave, lane, hasx, allow, em, task_dbg);
     }
     PRF_STAMP(3);
-    __syncthreads();  // the image is dead from here on: the row list may lie there
-    if (hasx) {
-        // A tile with N in reach kept its not-ACGT plane where the linear window belongs.  Now that the scan is over the
-        // windows of all three linear planes are staged -- H and L in the window's place, X in the dead image behind the row
-        // and flag lists -- so that this tile, too, verifies from LDS (a look at the global planes is a memory round trip).
-        constexpr u32 xwin_off = (u32)SMEM_HDR + (u32)ROW_CAP_LDS * 16u + 4u * 512u * 2u;
-        static_assert(xwin_off + LW * 8 <= SMEM_HDR + 2 * RG * NC * 16, "the X window must fit the dead image");
-        prf_lds_u64 *xwin = (prf_lds_u64 *)(prf_smem + xwin_off);
-        // (wave-uniform bases + an opaque 32-bit thread offset, as in StageRegs::load)
+    __syncthreads();  // the image is dead from here on
+    // ---- 3a. R1 <- the window of the linear planes H and L (tile - 128 .. tile + 65536 + 1536 positions) by DMA, in 16-byte
+    // units: unit u < LW/2 is H's word pair u, the others L's; piece = 64 units = 1 KiB; piece i of wave w is w + 4 i.
+    {
         const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;
-        const u64 *wh = g.H + w0, *wl = g.L + (w0 - LW), *wx = g.X + (w0 - 2 * LW);
-        u32 ut = (u32)tid;
-        asm volatile("" : "+v"(ut));
-        constexpr int NR = (3 * LW + NTH - 1) / NTH;
-        u64 v[NR];
-        static_for<0, NR>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const u32 idx = ut + (u32)(i * NTH), ob = idx * 8u;
-            if constexpr ((i + 1) * NTH <= LW) v[i] = StageRegs<NC>::ld8(wh, ob);
-            else if constexpr (i * NTH >= LW && (i + 1) * NTH <= 2 * LW) v[i] = StageRegs<NC>::ld8(wl, ob);
-            else if constexpr (i * NTH >= 2 * LW && (i + 1) * NTH <= 3 * LW) v[i] = StageRegs<NC>::ld8(wx, ob);
-            else v[i] = idx < (u32)LW ? StageRegs<NC>::ld8(wh, ob) : (idx < 2u * LW ? StageRegs<NC>::ld8(wl, ob) : (idx < 3u * LW ? StageRegs<NC>::ld8(wx, ob) : 0ull));
+        const u64 *wh = g.H + w0, *wl = g.L + w0;
+        constexpr u32 UNITS = (u32)LW;  // 2 planes x LW / 2
+        constexpr u32 PIECES = (UNITS + 63u) / 64u;
+        static_for<0, 5>([&](auto ic) {
+            constexpr u32 i = (u32)decltype(ic)::value;
+            const u32 piece = (u32)wave + 4u * i;
+            if (piece < PIECES) {  // wave-uniform
+                const u32 u = piece * 64u + (u32)lane;
+                const u64 *src = u < (u32)LW / 2u ? wh + 2u * u : wl + 2u * (u - (u32)LW / 2u);
+                if (u < UNITS) dma16(src, R1_OFF + piece * 1024u);
+            }
         });
-        static_for<0, NR>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const u32 idx = ut + (u32)(i * NTH);
-            if (idx < 2u * LW) lin[idx] = v[i];
-            else if (idx < 3u * LW) xwin[idx - 2u * LW] = v[i];
-        });
-        if (tid == 0) {
-            TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
-            tcw->has_lin = 1u;
-            tcw->xwin_off = xwin_off;
-        }
-        __syncthreads();
+        // the row list is padded to its capacity with the largest key: no bounds test per key when the rows are ranked
+        // (rows that the scan's overflow paths have listed already stay; the verification appends behind them)
+        const u32 n0 = cnt[CNT_ROWS];
+        for (u32 i = (u32)tid; i < (u32)ROW_CAP_LDS; i += (u32)NTH)
+            if (i >= n0) keys[i] = 0xFFFFFFFFu;
+        if (tid == 0) reinterpret_cast<TileCtx *>(prf_smem)->has_lin = 1u;
     }
+    __syncthreads();  // (waits for the window's DMA too)
     PRF_STAMP(4);
 
-    // ---- 3. verify what is left in the lists, all waves together: every candidate -> a row in the tile's LDS list, or nothing ----
+    // ---- 3b. verify, all waves together: every candidate -> a row in the tile's list, or nothing ----
     // (the record waves are the critical path of this phase, the flag waves wait for them at the barrier below)
     set_prio(wave < MAX_WAVES / 2 ? (g.plan.prio >> 6) & 3u : (g.plan.prio >> 8) & 3u);
-    u32 n_flags = verify_all((prf_lds_cu64 *)recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (u32)tid, task_dbg);
-    set_prio((g.plan.prio >> 10) & 3u);
-    if (tid == 0) {
-        // statistics: candidates looked at = (stream, exact task) flags (thread 0 holds their number) + group-task records
-        n_flags += *(prf_lds_u32 *)(prf_smem + 168) + hdr_cnt[0] + hdr_cnt[1] + hdr_cnt[2] + hdr_cnt[3];
-        if (n_flags)
-            atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
+    {
+        const u32 nr = cnt[CNT_RECS];
+        const u32 *xw = hasx ? reinterpret_cast<const u32 *>(g.X + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE)) : nullptr;
+        u32 n_flags = verify_all((prf_lds_cu64 *)recs, nr < (u32)REC_CAP ? nr : (u32)REC_CAP, (prf_lds_cu32 *)bitems, g.plan.n_group_k, xw, (u32)tid, task_dbg);
+        if (tid == 0) {
+            // statistics: candidates looked at = (stream, exact task) flags (thread 0 holds their number) + group-task records
+            n_flags += nr + cnt[CNT_EARLY];
+            if (n_flags)
+                atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
+        }
     }
+    set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
         const u32 sn = (first_ticket + (u32)ticket) * 8u + xcd;
         next_words[0] = sn;
         next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
     }
     PRF_STAMP(5);
-    __syncthreads();
+    __syncthreads();  // the window is dead from here on
     PRF_STAMP(6);
-    const u64 nw = *(prf_lds_cu64 *)next_words;  // (one read)
+    const u64 nw = *(prf_lds_u64 *)next_words;  // (one read)
     slot_next = (u32)__builtin_amdgcn_readfirstlane((int)(u32)nw);
     const u32 entry_next = (u32)(nw >> 32);
+    const u32 n_rows = (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_ROWS]);
+    const u32 n_long = (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_LONG]);
+    u64 *slab = g.slabs + (u64)slot * g.slab_cap;
+    const u32 n_store = n_rows < g.slab_cap ? n_rows : g.slab_cap;
+    bool unsorted = false;
 
-    // the next tile's staging data: loads issued now, consumed at the top of the loop
+    // ---- 4. the tile's rows, sorted by (start, end), into its slab.  Rank of a row = number of rows with a smaller key; keys
+    // are distinct ((start, end) pairs never collide between motif sizes).
+    if (n_rows > (u32)ROW_CAP_LDS) {
+        // A dense tile (the reference's golden chr22 BED has tiles of 750 rows): the rows behind the list went to the slab as
+        // they came.  All of them are collected in R1 -- the window is dead -- and ranked there.
+        constexpr u32 R1_ROWS = R1_BYTES / 8u;
+        static_assert(R1_ROWS % 32u == 0, "padding of the dense-tile key list");
+        if (n_store <= R1_ROWS) {
+            prf_lds_u32 *k2 = (prf_lds_u32 *)(prf_smem + R1_OFF), *v2 = k2 + R1_ROWS;
+            for (u32 i = (u32)tid; i < (u32)ROW_CAP_LDS; i += (u32)NTH) {
+                k2[i] = keys[i];
+                v2[i] = keys[ROW_CAP_LDS + i];
+            }
+            for (u32 i = (u32)ROW_CAP_LDS + (u32)tid; i < n_store; i += (u32)NTH) {
+                const u64 r = slab[i];
+                k2[i] = (u32)r;
+                v2[i] = (u32)(r >> 32);
+            }
+            for (u32 i = n_store + (u32)tid; i < ((n_store + 31u) & ~31u); i += (u32)NTH) k2[i] = 0xFFFFFFFFu;
+            __syncthreads();
+            typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
+            prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)k2;
+            for (u32 r = (u32)tid; r < n_store; r += (u32)NTH) {
+                const u32 mine = k2[r], kv = v2[r];
+                u32 rank = 0;
+                for (u32 c0 = 0; 4u * c0 < n_store; c0 += 8u) {
+#pragma unroll
+                    for (u32 j = 0; j < 8u; j++) {
+                        const prf_u32x4 v = k4[c0 + j];
+                        rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+                    }
+                }
+                slab[rank] = (u64)mine | ((u64)kv << 32);
+            }
+            __syncthreads();  // R1 is refilled below
+        } else {
+            // more rows than R1 holds (no genome does that): the list goes to the slab as it is, the host sorts
+            for (u32 i = (u32)tid; i < (u32)ROW_CAP_LDS && i < n_store; i += (u32)NTH) slab[i] = (u64)keys[i] | ((u64)keys[ROW_CAP_LDS + i] << 32);
+            unsorted = true;
+        }
+    }
+
+    // the next tile's staging data: the image's DMA and the virtual lanes' loads are issued now and land while the rows are ranked
     // (every register is written on both paths: dead from the stage to here, not carried around the loop)
-    if (slot_next < g.n_launch) sr.load(g, entry_next, tid);
+    if (slot_next < g.n_launch) sr.load(g, entry_next, tid, wave, R1_OFF);
     else sr.clear();
 
-    // ---- 4. the tile's rows, sorted by (start, end), into its slab: [rows written directly, unsorted][the LDS list, sorted].
-    // Rank of a row = number of rows of the list with a smaller key; keys are distinct ((start, end) pairs never collide
-    // between motif sizes).
-    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
-    // (the slab through the kernel argument, not through the pointer in the LDS context: that one is generic, and a FLAT
-    // store counts as an LDS operation too -- the next LDS wait would sit behind the prefetch loads just issued)
-    prf_hit_dev *slab = g.slabs + (u64)slot * g.slab_cap;
-    u32 n_listed = *smem_row_cnt();
-    u32 n_direct = *smem_direct_cnt();
-    if (n_direct && n_listed + n_direct <= (u32)ROW_CAP_LDS && n_direct <= tc.slab_cap) {
-        // Rows that went straight to the slab (a wave emptied its record list in the middle of the scan) and still fit the
-        // list: read them back and sort them with the others -- the tile stays sorted.
-        if ((u32)tid < n_direct) {
-            const prf_hit_dev h = slab[tid];
-            const u64 a = h.start + tc.contig_base, end = h.end + tc.contig_base, span = end - a;
-            smem_row_keys()[n_listed + tid] = ((u32)(a - tc.tile_base) << 16) | (span < 65535ull ? (u32)span : 65535u);
-            smem_row_ks()[n_listed + tid] = h.k;
-            smem_row_ends()[n_listed + tid] = end;
-        }
-        __syncthreads();  // wave-uniform condition: every thread gets here
-        n_listed += n_direct;
-        n_direct = 0;
-    }
-    const u32 n_sorted = n_listed < (u32)ROW_CAP_LDS ? n_listed : (u32)ROW_CAP_LDS;
-    const u32 n_rows = n_sorted + n_direct;  // rows beyond the list's capacity were counted in n_direct
-    if (n_sorted) {
+    if (n_rows && n_rows <= (u32)ROW_CAP_LDS) {
         // P = 256 / n threads per row (a power of two, adjacent lanes): each counts the smaller keys of its share of the
-        // list, the shares are added up across the P lanes.  Dependent LDS round trips are what this phase costs (~500 cycles
-        // each with the other workgroups' scans on the CU): the row's own key, end and motif size and the first 32 keys of
-        // the lane's share are ONE batch of reads; the shares are added with DPP moves, not LDS shuffles.
-        // (P <= 8: eight reads of a lane, 4 P keys apart, stay inside the 256 padded keys)
-        const u32 lg = n_sorted > 128u ? 0u : (n_sorted > 64u ? 1u : (n_sorted > 32u ? 2u : 3u));
-        const u32 P = 1u << lg, row = (u32)tid >> lg, part = (u32)tid & (P - 1u);
-        prf_lds_u32 *keys = smem_row_keys();
-        // the list is padded to its capacity with the largest key: no bounds test per key in the loop below
-        if ((u32)tid >= n_sorted) keys[tid] = 0xFFFFFFFFu;
-        __syncthreads();  // (n_sorted is the same for every thread)
+        // list, the shares are added up across the P lanes.  Dependent LDS round trips are what this phase costs: the row's own
+        // key and motif size and the first 32 keys of the lane's share are ONE batch of reads; the shares are added with DPP
+        // moves, not LDS shuffles.  More than 256 rows: two passes.
+        const u32 lg = n_rows > 128u ? 0u : (n_rows > 64u ? 1u : (n_rows > 32u ? 2u : 3u));
+        const u32 P = 1u << lg, part = (u32)tid & (P - 1u);
         typedef __attribute__((address_space(3))) const prf_u32x4 prf_lds_ckey4;
         prf_lds_ckey4 *k4 = (prf_lds_ckey4 *)keys;
-        const u32 r = row < n_sorted ? row : 0u;  // (lanes without a row read row 0: harmless)
-        const u32 mine = keys[r];
-        const u64 end = smem_row_ends()[r];
-        const u32 kk = smem_row_ks()[r];
-        u32 rank = 0;
-        // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, eight reads in flight
-        for (u32 c0 = part; 4u * c0 < n_sorted; c0 += 8u * P) {
-            prf_u32x4 v[8];
+        for (u32 row0 = 0; row0 < n_rows; row0 += (u32)NTH >> lg) {
+            const u32 row = row0 + ((u32)tid >> lg);
+            const u32 r = row < n_rows ? row : 0u;  // (lanes without a row read row 0: harmless)
+            const u32 mine = keys[r];
+            const u32 kv = keys[ROW_CAP_LDS + r];
+            u32 rank = 0;
+            // part p takes the keys 4 p .. 4 p + 3, then 4 P further on, ...: one 16-byte read per four keys, eight reads in flight
+            for (u32 c0 = part; 4u * c0 < n_rows; c0 += 8u * P) {
+                prf_u32x4 v[8];
 #pragma unroll
-            for (u32 j = 0; j < 8u; j++) v[j] = k4[c0 + j * P];
-            // (all eight reads in flight before the first compare: left alone the compiler issues them two at a time, a
-            // round trip per pair, to save registers it does not need here)
-            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+                for (u32 j = 0; j < 8u; j++) v[j] = k4[c0 + j * P];
+                // (all eight reads in flight before the first compare: left alone the compiler issues them two at a time)
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
-            for (u32 j = 0; j < 8u; j++) {
-                rank += v[j].x < mine ? 1u : 0u;  // (keys past the list are 0xFFFFFFFF: never smaller)
-                rank += v[j].y < mine ? 1u : 0u;
-                rank += v[j].z < mine ? 1u : 0u;
-                rank += v[j].w < mine ? 1u : 0u;
+                for (u32 j = 0; j < 8u; j++) {
+                    rank += v[j].x < mine ? 1u : 0u;  // (keys past the list are 0xFFFFFFFF: never smaller)
+                    rank += v[j].y < mine ? 1u : 0u;
+                    rank += v[j].z < mine ? 1u : 0u;
+                    rank += v[j].w < mine ? 1u : 0u;
+                }
             }
-        }
-        // sum over the P adjacent lanes of a row (wave-uniform P): xor 1, xor 2 by quad permutes; after those all lanes of a
-        // quad agree, so the half-row and row mirrors pair the right partners for 4 and 8
-        if (P >= 2u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0xB1, 0xF, 0xF, true);
-        if (P >= 4u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x4E, 0xF, 0xF, true);
-        if (P >= 8u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x141, 0xF, 0xF, true);
-        const u32 dst = n_direct + rank;
-        if (row < n_sorted && part == 0 && dst < tc.slab_cap) {
-            prf_hit_dev h;
-            h.start = tc.tile_base + (mine >> 16) - tc.contig_base;
-            h.end = end - tc.contig_base;
-            h.k = kk;
-            h.contig = tc.contig;
-            slab[dst] = h;
+            // sum over the P adjacent lanes of a row (wave-uniform P): xor 1, xor 2 by quad permutes; after those all lanes of a
+            // quad agree, so the half-row and row mirrors pair the right partners for 4 and 8
+            if (P >= 2u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0xB1, 0xF, 0xF, true);
+            if (P >= 4u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x4E, 0xF, 0xF, true);
+            if (P >= 8u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x141, 0xF, 0xF, true);
+            if (row < n_rows && part == 0 && rank < g.slab_cap) slab[rank] = (u64)mine | ((u64)kv << 32);
         }
     }
+    if ((u32)tid < n_long && (u32)tid < PRF_LONG_PER_TILE)
+        g.long_ends[(u64)slot * PRF_LONG_PER_TILE + (u32)tid] = ((prf_lds_u64 *)(prf_smem + HDR_LONG))[tid];
     if (tid == 0) {
         g.slab_count[slot] = n_rows;
-        const u32 stored = n_rows < tc.slab_cap ? n_rows : tc.slab_cap;
-        if (stored) {  // rows in front of a gather workgroup's slots: two levels of sums
-            atomicAdd(&g.block_sum[slot >> g.gather_shift], stored);
-            atomicAdd(&g.block_sum[g.super_off + ((slot >> g.gather_shift) / PRF_GATHER_SUPER)], stored);
+        if (n_store) {  // rows in front of a gather workgroup's slots: two levels of sums
+            atomicAdd(&g.block_sum[slot >> g.gather_shift], n_store);
+            atomicAdd(&g.block_sum[g.super_off + ((slot >> g.gather_shift) / PRF_GATHER_SUPER)], n_store);
         }
-        if (n_rows > tc.slab_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
-        if (n_direct) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
+        if (n_rows > g.slab_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
+        if (unsorted) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
+        if (n_long > PRF_LONG_PER_TILE) atomicMax(&g.counters[PRF_CNT_LONG_OVF], (u64)n_long);
     }
     PRF_STAMP(7);
 #ifdef PRF_STAMPS
     if (g.dbg && lane == 0) g.dbg[((u64)slot * MAX_WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();  // the header, the row list and the image region are rewritten for the next tile
+    // (no barrier here: the next round's first barrier separates this tile's reads of the row list from the next tile's writes)
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Row gather: the slabs, in launch (= position) order, become ONE compact array.  Workgroup w owns the launch slots
-// [8 w, 8 w + 8): the rows in front of them are sums the scan kernel has added up (two atomics per tile: per 8 slots and per
-// 512 slots); it scans its own 8 counts and copies its slabs word by word, four loads in flight per thread.  The workgroup
-// that finishes last hands the counter block to the host (mapped memory, no copy call), and clears the sums and the
-// counter block of the next scan (no memset call).
+// Row gather: the slabs (8-byte rows, sorted per tile), in launch (= position) order, become ONE compact array of 24-byte
+// rows.  Workgroup w owns the launch slots [w << shift, (w + 1) << shift): the rows in front of them are sums the scan kernel
+// has added up (two atomics per tile: per gather workgroup and per 64 of them); it scans its own counts and writes its rows
+// word by word -- three threads decode a row, each stores one of its words: coalesced 8-byte stores, four loads in flight.
+// The workgroup that finishes last hands the counter block to the host (mapped memory, no copy call), and clears the sums
+// and the counter block of the next scan (no memset call).
 __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     __shared__ u64 part[4];
-    __shared__ u32 offs[PRF_GATHER_SLOTS_MAX + 1];  // in words (3 per row)
+    __shared__ u32 offs[PRF_GATHER_SLOTS_MAX + 1];   // in rows
+    __shared__ u64 tbase[PRF_GATHER_SLOTS_MAX];      // first position of the slot's tile
+    __shared__ u64 cbase[PRF_GATHER_SLOTS_MAX];      // first position of its contig
+    __shared__ u32 contig[PRF_GATHER_SLOTS_MAX];
     __shared__ u64 ticket_lds;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) or 64
+    const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) .. 64
     const u32 first = blockIdx.x << g.gather_shift;
     const u32 my_super = blockIdx.x / PRF_GATHER_SUPER;
     u64 before = 0;
@@ -1353,9 +1283,10 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     if (tid < blockIdx.x - my_super * PRF_GATHER_SUPER) before += g.block_sum[my_super * PRF_GATHER_SUPER + tid];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
-    if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel)
-        u32 c = (tid < n_slots && first + tid < g.n_launch) ? g.slab_count[first + tid] : 0u;
-        c = 3u * (c < g.slab_cap ? c : g.slab_cap);
+    if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel), the slots' tiles and contigs
+        const bool live = tid < n_slots && first + tid < g.n_launch;
+        u32 c = live ? g.slab_count[first + tid] : 0u;
+        c = c < g.slab_cap ? c : g.slab_cap;
         u32 incl = c;
         for (int o = 1; o < 64; o <<= 1) {
             const u32 up = __shfl_up(incl, o, 64);
@@ -1363,38 +1294,60 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
         }
         offs[tid + 1] = incl;
         if (tid == 0) offs[0] = 0;
+        if (live) {
+            const u64 tile = (g.flat_base != ~0u ? g.flat_base + first + tid : g.launch_list[first + tid]) & ~PRF_LAUNCH_MIXED;
+            const uint4 ti = g.tile_info[tile];
+            tbase[tid] = tile * PRF_TILE;
+            cbase[tid] = (u64)ti.z | ((u64)ti.w << 32);
+            contig[tid] = ti.x;
+        }
     }
     __syncthreads();
     const u64 base0 = part[0] + part[1] + part[2] + part[3];  // rows in front of this workgroup's slots
-    const u32 n_words = offs[n_slots];
+    const u32 n_mine = offs[n_slots];
     // rows beyond the capacity stay behind: the host sees the total beyond the capacity, grows the array, rescans
     const u64 room_rows = base0 < g.rows_cap ? g.rows_cap - base0 : 0;
-    const u64 room_words = 3ull * room_rows;
-    const u32 n_copy = (u64)n_words < room_words ? n_words : (u32)room_words;
+    const u32 n_copy = 3u * ((u64)n_mine < room_rows ? n_mine : (u32)room_rows);  // words
     u64 *dst = reinterpret_cast<u64 *>(g.rows + base0);
     for (u32 w0 = tid; w0 < n_copy; w0 += 1024u) {
-        u64 v[4];
+        u64 sr[4];
+        u32 sl[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const u32 w = w0 + 256u * (u32)j;
-            v[j] = 0;
+            sr[j] = 0;
+            sl[j] = 0;
             if (w < n_copy) {
-                u32 lo = 0, hi = n_slots;  // the slot whose words hold w: offs[lo] <= w < offs[lo + 1]
+                const u32 row = w / 3u;
+                u32 lo = 0, hi = n_slots;  // the slot that holds the row: offs[lo] <= row < offs[lo + 1]
                 while (hi - lo > 1) {
                     const u32 mid = (lo + hi) >> 1;
-                    if (offs[mid] <= w) lo = mid; else hi = mid;
+                    if (offs[mid] <= row) lo = mid; else hi = mid;
                 }
-                v[j] = reinterpret_cast<const u64 *>(g.slabs + (u64)(first + lo) * g.slab_cap)[w - offs[lo]];
+                sl[j] = lo;
+                sr[j] = g.slabs[(u64)(first + lo) * g.slab_cap + (row - offs[lo])];
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const u32 w = w0 + 256u * (u32)j;
-            if (w < n_copy) dst[w] = v[j];
+            if (w < n_copy) {
+                const u32 which = w % 3u, key = (u32)sr[j], kv = (u32)(sr[j] >> 32), lo = sl[j];
+                const u64 start = tbase[lo] + (key >> 16);
+                u64 v;
+                if (which == 0) v = start - cbase[lo];
+                else if (which == 2) v = (u64)(kv & 0xFFFFu) | ((u64)contig[lo] << 32);
+                else {
+                    const u32 li = kv >> 16;  // 1 + index of the true end of a row whose span is clipped
+                    const u64 end = li ? g.long_ends[(u64)(first + lo) * PRF_LONG_PER_TILE + (li - 1u)] : start + (key & 0xFFFFu);
+                    v = end - cbase[lo];
+                }
+                dst[w] = v;
+            }
         }
     }
     // the workgroup of the last slots knows the total
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_words / 3u);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_mine);
     __syncthreads();  // every wave's stores and atomics are issued; the barrier waits for outstanding memory operations
     // Finishing tickets in two levels (one word takes ~90 atomics per microsecond: thousands of workgroups on ONE ticket word
     // would cost more than the copy): a ticket per 64 workgroups, and the last of each 64 draws a global one.
@@ -1432,7 +1385,6 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
         if (tid == 0) __hip_atomic_store(&g.host_counters[PRF_CNT_N], g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-
 // ---------------------------------------------------------------------------------------------------
 // ASCII -> bit-sliced planes.  One wave per tile; lane l, for bit b = 0..31, reads the 32 consecutive
 // bytes of stream b*64+l (a wave reads 2 KiB contiguous per b) and spreads them over its 32 row words.
@@ -1617,10 +1569,27 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     const u32 need_nc = 64 + reach / T;  // row r of a lane's extended stream lies in virtual lane + r / 32
     plan->nc = need_nc <= 72 ? 72 : 80;  // the widths the kernel is instantiated for
     plan->cof_words = (kmax + 1 + 3) & ~3u;  // <= PRF_VMAX_K + 4: the table is declared with that many entries
-    plan->lds_bytes = (u32)(SMEM_HDR + (size_t)2 * RG * plan->nc * sizeof(uint4) + (size_t)2 * LW * sizeof(u64) +
-                            (size_t)MAX_WAVES * REC_PER_WAVE * sizeof(u64) + (size_t)(plan->n_exact * 64 + 16 + plan->n_group_k) * sizeof(u32) +
+    // header, R1 (image / window), records, row list, all-N masks, flag lists + counts, boundary items, cofactor table
+    plan->lds_bytes = (u32)(SMEM_HDR + (size_t)2 * RG * plan->nc * sizeof(uint4) + (size_t)REC_CAP * sizeof(u64) +
+                            (size_t)2 * ROW_CAP_LDS * sizeof(u32) + 256 + (size_t)(plan->n_exact * 64 + 16 + plan->n_group_k) * sizeof(u32) +
                             (size_t)plan->cof_words * sizeof(u32));
+    plan->per_cu = 0;  // (set at the first launch: the occupancy the runtime reports for this much LDS)
     return need_nc <= 80;
+}
+
+// persistent workgroups: as many as are resident at once (LDS- and register-bound: 6 per CU at most)
+static u32 resident_per_cu(u32 nc, u32 lds) {
+    int n = 0;
+    hipError_t e = nc == 72 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, prf_vscan_kernel<72>, NTH, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, prf_vscan_kernel<80>, NTH, lds);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = (int)std::max(1u, (160u * 1024u) / std::max(1u, lds + 1280u));
+    }
+    // (MI355X_MICROARCH.md: 256-thread workgroups are admitted up to floor(800 / (ceil(sgpr / 16) * 16 + 16)) per CU, which the
+    // API overstates by one for 81 .. 112 SGPRs; the kernel is built for six.  A grid larger than what is resident is harmless
+    // here -- no workgroup ever waits for another -- it only makes the launch slots taken "by index" start late.)
+    return (u32)std::min(n, 6);
 }
 
 hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
@@ -1628,7 +1597,6 @@ hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
     // PRF_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, to measure the scan at a lower occupancy
     static const u32 lds_pad = getenv("PRF_LDS_PAD") ? (u32)atoi(getenv("PRF_LDS_PAD")) : 0u;
     const u32 lds = args.plan.lds_bytes + lds_pad;
-    // persistent workgroups: as many as are resident at once (LDS- and register-bound: 4 per CU at most)
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1636,8 +1604,14 @@ hipError_t prf_vertical_launch(hipStream_t s, const prf_vscan_args &args) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         n_cu = prop.multiProcessorCount;
     }
-    const u32 per_cu = std::max(1u, std::min(4u, (160u * 1024u) / std::max(1u, lds)));
-    const dim3 grid(std::min(args.n_launch, per_cu * (u32)n_cu)), block(NTH);
+    static u32 cache_lds = ~0u, cache_nc = 0, cache_per_cu = 0;
+    if (cache_lds != lds || cache_nc != args.plan.nc) {
+        cache_per_cu = resident_per_cu(args.plan.nc, lds);
+        cache_lds = lds;
+        cache_nc = args.plan.nc;
+        if (getenv("PRF_DEBUG")) fprintf(stderr, "[prf] fused kernel: nc %u, %u bytes of LDS, %u workgroups per CU\n", args.plan.nc, lds, cache_per_cu);
+    }
+    const dim3 grid(std::min(args.n_launch, cache_per_cu * (u32)n_cu)), block(NTH);
     switch (args.plan.nc) {
         case 72: hipLaunchKernelGGL((prf_vscan_kernel<72>), grid, block, lds, s, args); break;
         case 80: hipLaunchKernelGGL((prf_vscan_kernel<80>), grid, block, lds, s, args); break;

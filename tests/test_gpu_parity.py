@@ -303,17 +303,17 @@ def test_very_long_runs_flush_the_candidate_lists(ctx):
 
 
 def test_row_slab_overflow_grows_the_slabs(ctx):
-    """More rows in one tile than the default per-tile row slab holds (512) but fewer candidate records than
-    the LDS list (1024): the scan must grow the slabs and retry on the fused path."""
+    """More rows in one tile than the default per-tile row slab holds (1024): the scan must grow the slabs and retry on the
+    fused path."""
     import collections
-    unit = b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG"
-    seq = unit * 2500
+    unit = b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAG"
+    seq = unit * 5000
     rows, stats = ctx.scan([seq], 1, 6, 3, 9)
     assert stats.path == 1
     got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
     assert got == oracle_rows(seq, 1, 6, 3, 9)
     per_tile = collections.Counter(s // 65536 for s, _e, _k in got)
-    assert max(per_tile.values()) > 512
+    assert max(per_tile.values()) > 1024
 
 
 def test_errors_cross_the_boundary_cleanly(ctx):
@@ -738,9 +738,19 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
         assert np.array_equal(multi_gpu.unpack_rows(words.cpu().numpy(), len(rows), 4, g.contig_bases(), prf_native.tile_positions()), rows)
     finally:
         g.free()
+    # dense tiles (round 3): 799 rows per tile -- more than the LDS row list holds (the densest tile of the reference's golden
+    # chr22 BED has 748) -- are collected and ranked in the dead image region: still sorted on the device, no second scan
     dense = (b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGGCTAACGTTAGCCATGGATCAAGCTTGCATGCCTGCAGGTCGACTCTAGAG") * 2500
     rows, st = ctx.scan([dense], 1, 6, 3, 9)
-    assert st.sorted_on_device == 0 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(dense, 1, 6, 3, 9)
+    assert st.sorted_on_device == 1 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(dense, 1, 6, 3, 9)
+    # 2048 rows per tile: beyond the default slab (1024): the slabs grow, the scan is repeated, the rows are still sorted on the device
+    denser = (b"ACACACACACAC" + b"GTTGCAGATCCGTAGCTAGG") * 6000
+    rows, st = ctx.scan([denser], 1, 6, 3, 9)
+    assert st.sorted_on_device == 1 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(denser, 1, 6, 3, 9)
+    # 3277 rows per tile: more than the image region holds -- no genome does that -- the host sorts
+    densest = (b"ACACACACACAC" + b"GTTGCAGA") * 9000
+    rows, st = ctx.scan([densest], 1, 6, 3, 9)
+    assert st.sorted_on_device == 0 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(densest, 1, 6, 3, 9)
 
 
 def test_parts_of_one_genome_scanned_separately_add_up_to_the_whole_scan(ctx):
