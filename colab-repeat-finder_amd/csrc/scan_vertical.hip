@@ -65,11 +65,12 @@ constexpr int LIN_POST = 24;                                  // ... and after i
 constexpr int LW = (int)PRF_TILE_WORDS + LIN_PRE + LIN_POST;  // words per plane in the LDS window
 static_assert(LW % 2 == 0, "the window travels in 16-byte pieces");
 constexpr u32 WIN_LEAD = 64u * (u32)LIN_PRE;                  // window positions in front of the tile
-constexpr int REC_CAP = 256;                                  // group-task candidate records of a tile (one LDS list)
+constexpr int REC_CAP = 192;                                  // group-task candidate records of a tile (one LDS list)
+constexpr int FLAG_CAP = 1024;                                // (stream, exact task) flags of a tile (one LDS list, 2 bytes each)
+constexpr int SLOW_CAP = 32;                                  // candidates of a tile that leave the LDS window: finished after the others
 constexpr int MAX_WAVES = PRF_VMAX_WAVES;
 constexpr int NTH = 64 * MAX_WAVES;                           // threads per workgroup, always
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
-constexpr u32 FLAGS_PER_TASK = 128;                           // flags (lane, stream) an exact task's list holds: 256 B per task
 constexpr int ROW_CAP_LDS = 448;                              // rows of a tile in the LDS list (more: the slab holds the rest, sorted in R1)
 static_assert(ROW_CAP_LDS % 32 == 0, "the rank loop reads the padded key list 32 keys at a time");
 
@@ -91,12 +92,13 @@ __device__ __forceinline__ u64 make_rec(u32 lane, u32 k, u32 sc, u32 word) {
 
 // dynamic LDS: [header][R1: image / window][recs][row keys][row motif sizes][all-N stream masks][flag lists, counts][boundary items][cofactors]
 extern __shared__ __attribute__((aligned(16))) unsigned char prf_smem[];
-constexpr int SMEM_HDR = 208;
+constexpr int SMEM_HDR = 240;
 // header words: 128.. two sets of tile counters used alternately (a set is reset while the other one is still read)
-constexpr int HDR_CNT = 128;       // [parity][4] u32: rows, records, records verified early, long rows
-constexpr int HDR_NEXT = 160;      // {next launch slot, its entry}
-constexpr int HDR_LONG = 168;      // [PRF_LONG_PER_TILE] u64: true ends of the rows whose span is clipped
-constexpr u32 CNT_ROWS = 0, CNT_RECS = 1, CNT_EARLY = 2, CNT_LONG = 3;
+constexpr int HDR_CNT = 128;       // [parity][8] u32
+constexpr int HDR_NEXT = 192;      // {next launch slot, its entry}
+constexpr int HDR_LONG = 200;      // [PRF_LONG_PER_TILE] u64: true ends of the rows whose span is clipped
+constexpr u32 CNT_ROWS = 0, CNT_RECS = 1, CNT_EARLY = 2, CNT_LONG = 3, CNT_FLAGS = 4, CNT_SLOW = 5,
+              CNT_ROWS0 = 6, CNT_LONG0 = 7;  // rows / long rows listed before the verification began (the scan's overflow paths)
 
 // LDS is addressed through explicit address-space pointers everywhere: a generic pointer that the compiler cannot trace back
 // to prf_smem becomes a flat_load, which is slower and waits on both memory counters.
@@ -136,9 +138,8 @@ struct TileCtx {
     u32 has_lin;              // the linear window is staged (after the scan)
     u32 keys_off;             // byte offset of the row list (keys, then motif sizes) in LDS
     u32 cof_off;              // byte offset of the cofactor table in LDS
-    u32 hotw_off;             // byte offset of the exact tasks' flag lists in LDS, the counts behind them
-    u32 n_exact;              // exact tasks of the plan: motif sizes k_exact0 .. k_exact0 + n_exact - 1, task index = k - k_exact0
-    u32 k_exact0;
+    u32 slow_off;             // byte offset of the list of deferred candidates in LDS
+    u32 k_exact0;             // exact tasks of the plan: motif sizes k_exact0 ..., task index = k - k_exact0
     u32 cnt_off;              // byte offset of this tile's counter set in LDS
 };
 static_assert(sizeof(TileCtx) <= 128, "TileCtx must fit its LDS header slot");
@@ -343,20 +344,54 @@ __device__ __forceinline__ u32 min_matches32(u32 k, u32 min_repeats, u32 min_spa
     return a > b ? a : b;
 }
 
-// end of the run at motif size k that matches up to window position `from` (global position returned); leaves the
-// window -> the general routine
-__device__ __forceinline__ u64 win_run_end(const WinCtx &wc, u32 from, u32 k) {
+// The verification loops below contain NO call: a call site in a loop makes the register allocator keep everything that is
+// live around it in the 24 callee-saved registers a six-workgroup kernel has, or in scratch memory -- the first version of
+// this kernel spilled the loops' own state that way (412 scratch operations per tile).  The few candidates that cannot be
+// finished inside the LDS window (a run that reaches past it, the first stream of a clean tile, whose look-back lies in
+// front of the tile) are put on a short list and finished by the general routine once the loops are over; a tile with more
+// of them than the list holds is verified again from its flags and records by the general routine alone.
+//   word 0: [39:0] start a (or the stream's first position), [48:40] k, [50:49] sc, [51] 1 = a whole stream (verify_stream),
+//           [52] the primitive-motif test is still to be done;   word 1: position the run is known to match up to
+__device__ __forceinline__ void defer(const TileCtx &tc, u64 a, u32 k, u32 sc, u32 whole_stream, u32 need_motif, u64 from) {
+    const u32 i = atomicAdd((u32 *)((prf_lds_u32 *)(prf_smem + tc.cnt_off) + CNT_SLOW), 1u);
+    if (i < (u32)SLOW_CAP) {
+        prf_lds_u64 *slow = (prf_lds_u64 *)(prf_smem + tc.slow_off);
+        slow[2u * i] = a | ((u64)k << 40) | ((u64)sc << 49) | ((u64)whole_stream << 51) | ((u64)need_motif << 52);
+        slow[2u * i + 1u] = from;
+    }
+}
+
+// one deferred candidate, by the general routine
+__device__ __noinline__ void slow_item(u64 w0, u64 from) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
+    const u64 a = w0 & ((1ull << 40) - 1ull);
+    const u32 k = (u32)(w0 >> 40) & 511u, sc = (u32)(w0 >> 49) & 3u;
+    if ((w0 >> 51) & 1ull) {
+        verify_stream(a, k, sc);
+        return;
+    }
+    if (((w0 >> 52) & 1ull) && motif_is_repeat(a, k)) return;
+    const u64 b = run_end(from, k);
+    if ((long long)(b - a) < prf_min_matches(k, tc.min_repeats, tc.min_span)) return;
+    emit_row(tc, a, b, k);
+}
+
+// end of the run at motif size k that matches up to window position `from`: true and the end (global position), or false
+// and `from` = the window position at which the walk leaves the window
+__device__ __forceinline__ bool win_run_end(const WinCtx &wc, u32 &from, u32 k, u64 &b) {
     for (;;) {
-        if (from + k + 96u > WIN_POS) return run_end(wc.win0 + from, k);
+        if (from + k + 96u > WIN_POS) return false;
         const u64 m2 = win_mismatch64(wc, from, k);
-        if (m2) return wc.win0 + from + (u64)__builtin_ctzll(m2);
+        if (m2) {
+            b = wc.win0 + from + (u64)__builtin_ctzll(m2);
+            return true;
+        }
         from += 64u;
     }
 }
 
-// motif [a, a+k) at window position a: a power of a shorter word?  (see motif_is_repeat)
+// motif [a, a+k) at window position a with a + 2 k + 96 <= WIN_POS: a power of a shorter word?  (see motif_is_repeat)
 __device__ __forceinline__ bool win_motif_is_repeat(const WinCtx &wc, u32 a, u32 k) {
-    if (a + 2u * k + 96u > WIN_POS) return motif_is_repeat(wc.win0 + a, k);
     for (u32 cf = wc.cof[k]; cf; cf >>= 8) {
         const u32 d = cf & 255u, need = k - d;
         bool has = true;
@@ -428,8 +463,14 @@ __device__ __forceinline__ void win_verify_flag(const TileCtx &tc, const WinCtx 
         if (rep) continue;
         const u32 a = q - 1u + i;
         const u64 after = m >> i;  // bit j = mismatch at a + j, known for j < 64 - i
-        const u64 b = after ? wc.win0 + a + (u64)__builtin_ctzll(after) : win_run_end(wc, a + (64u - i), k);
-        emit_row(tc, wc.win0 + a, b, k);
+        if (after) {
+            emit_row(tc, wc.win0 + a, wc.win0 + a + (u64)__builtin_ctzll(after), k);
+        } else {
+            u32 from = a + (64u - i);
+            u64 b;
+            if (win_run_end(wc, from, k, b)) emit_row(tc, wc.win0 + a, b, k);
+            else defer(tc, wc.win0 + a, k, 0u, 0u, 0u, wc.win0 + from);
+        }
     }
 }
 
@@ -461,8 +502,9 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
         // One batch of looks, issued together (one LDS round trip): the first 32 positions of the period test of up to three
         // cofactors, and the 64 positions behind the first look for the run's end.  Primitive motif first: most group
         // candidates are echoes of a short motif.
-        if (a + 2u * k + 96u > WIN_POS) {
-            if (motif_is_repeat(wc.win0 + a, k)) continue;
+        if (a + 2u * k + 96u > WIN_POS) {  // (the group itself is known to match)
+            defer(tc, wc.win0 + a, k, 0u, 0u, 1u, wc.win0 + (q - 32u + gb + 8u));
+            continue;
         } else {
             const u32 d1 = cof_k & 255u, d2 = (cof_k >> 8) & 255u, d3 = (cof_k >> 16) & 255u;
             const u32 mm1 = win_mismatch32(wc, a, d1 ? d1 : 1u);
@@ -491,7 +533,15 @@ __device__ __forceinline__ void win_verify_group(const TileCtx &tc, const WinCtx
             b = wc.win0 + (q - 32u + gb + 8u) + (u64)__builtin_ctzll(seen);
         } else {
             const u64 m2 = win_mismatch64(wc, q + 32u, k);  // (q + 32 + k + 96 <= WIN_POS for every stream of the tile)
-            b = m2 ? wc.win0 + (q + 32u) + (u64)__builtin_ctzll(m2) : win_run_end(wc, q + 96u, k);
+            if (m2) {
+                b = wc.win0 + (q + 32u) + (u64)__builtin_ctzll(m2);
+            } else {
+                u32 from = q + 96u;
+                if (!win_run_end(wc, from, k, b)) {
+                    defer(tc, wc.win0 + a, k, 0u, 0u, 0u, wc.win0 + from);
+                    continue;
+                }
+            }
         }
         if (b - (wc.win0 + a) < (u64)M) continue;
         emit_row(tc, wc.win0 + a, b, k);
@@ -511,20 +561,44 @@ __device__ __forceinline__ void boundary_item(const TileCtx &tc, const WinCtx &w
     if (c == 0 || c >= back) return;
     const u64 a = tile_end - c;
     const u64 hi = mm >> 32;  // bit i = mismatch at tile_end + i
-    const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : win_run_end(wc, WIN_LEAD + PRF_TILE + 32u, k);
+    u64 b;
+    if (hi) {
+        b = tile_end + (u64)__builtin_ctzll(hi);
+    } else {
+        u32 from = WIN_LEAD + PRF_TILE + 32u;
+        if (!win_run_end(wc, from, k, b)) {
+            defer(tc, a, k, 0u, 0u, 1u, wc.win0 + from);
+            return;
+        }
+    }
     if (b - a < (u64)min_matches32(k, tc.min_repeats, tc.min_span)) return;
+    static_assert(WIN_LEAD + PRF_TILE + 2u * PRF_VMAX_K + 96u <= WIN_POS, "the motif of a boundary item lies inside the window");
     if (!win_motif_is_repeat(wc, WIN_LEAD + PRF_TILE - c, k)) emit_row(tc, a, b, k);
 }
 
-__device__ __forceinline__ prf_lds_u32 *smem_cnt(u32 parity) { return (prf_lds_u32 *)(prf_smem + HDR_CNT) + 4u * parity; }
+// the same by the general routine (a tile that is verified again, see defer())
+__device__ __forceinline__ void boundary_general(const TileCtx &tc, u32 k, u32 S) {
+    const u64 tile_end = tc.tile_base + PRF_TILE;
+    const u32 back = 8u * S;
+    const u64 mm = tile_mismatch64(tile_end - 32, k);
+    const u32 lo = (u32)mm;
+    const u32 c = lo ? (u32)__builtin_clz(lo) : 32u;
+    if (c == 0 || c >= back) return;
+    const u64 a = tile_end - c;
+    const u64 hi = mm >> 32;
+    const u64 b = hi ? tile_end + (u64)__builtin_ctzll(hi) : run_end(tile_end + 32, k);
+    if (b - a < (u64)min_matches32(k, tc.min_repeats, tc.min_span)) return;
+    if (!motif_is_repeat(a, k)) emit_row(tc, a, b, k);
+}
+
+__device__ __forceinline__ prf_lds_u32 *smem_cnt(u32 parity) { return (prf_lds_u32 *)(prf_smem + HDR_CNT) + 8u * parity; }
 
 // Candidates -> rows, all waves together once the window is staged.
-//  * exact tasks left ballot-compacted lists of (stream, task) flags in LDS: one index space, dealt to the threads from
-//    thread 0 up;
+//  * exact tasks left ONE ballot-compacted list of (stream, task) flags in LDS, dealt to the threads from thread 0 up;
 //  * group-task records (one list) are taken by the upper two waves, alternately; the boundary items by the lower half, from
 //    its last thread down.
-// Returns the number of (stream, exact task) flags this thread looked at (statistics).
-__device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems, const u32 *xw, u32 tid, u64 *dbg) {
+__device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems, const unsigned short __attribute__((address_space(3))) *flags,
+                                           u32 n_flags, const u32 *xw, u32 tid, u64 *dbg) {
 #ifdef PRF_STAMPS
 #define PRF_VSTAMP(i) do { if (dbg && (tid & 63u) == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -539,38 +613,14 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_ld
     wc.win0 = tc.tile_base - WIN_LEAD;
     wc.min_repeats = tc.min_repeats;
     wc.min_span = tc.min_span;
-    // ---- exact tasks: every task left a ballot-compacted list of its flags (lane, stream bit) in LDS (Emit::push_flags).
-    // The flags of all tasks are one index space, dealt to the threads one by one: a wave runs the body about once, not as
-    // often as its unluckiest lane has flags.
-    u32 n_flags = 0;
-    if (tc.n_exact) {
-        constexpr u32 MAX_EXACT = SMALL_M - 1;  // motif sizes 1 .. 14 at most
-        typedef __attribute__((address_space(3))) const unsigned short prf_lds_cu16;
-        prf_lds_cu16 *lists = (prf_lds_cu16 *)(prf_smem + tc.hotw_off);
-        prf_lds_cu32 *counts = (prf_lds_cu32 *)(prf_smem + tc.hotw_off) + tc.n_exact * 64u;
-        u32 pre[MAX_EXACT + 1];
-        pre[0] = 0;
-        static_for<0, (int)MAX_EXACT>([&](auto ec) {  // (words past the last task are other data: masked)
-            constexpr u32 e = (u32)decltype(ec)::value;
-            const u32 c = counts[e];
-            pre[e + 1] = pre[e] + (e < tc.n_exact ? c : 0u);
-        });
-        const u32 total = pre[MAX_EXACT];
-        if (tid == 0) n_flags = total;
-        for (u32 idx = tid; idx < total; idx += (u32)NTH) {
-            u32 e = 0;
-            static_for<1, (int)MAX_EXACT>([&](auto ec) { e += idx >= pre[decltype(ec)::value] ? 1u : 0u; });
-            u32 first = 0;
-            static_for<1, (int)MAX_EXACT>([&](auto ec) {
-                constexpr u32 i = (u32)decltype(ec)::value;
-                first = e >= i ? pre[i] : first;
-            });
-            const u32 f = lists[e * FLAGS_PER_TASK + (idx - first)], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + e;
-            // (a clean tile's first stream looks at positions in front of the tile, where N is possible and nothing says so
-            // in the window: general routine)
-            if ((frl | fbit) || xw) win_verify_flag(tc, wc, frl, fbit, k);
-            else verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u);
-        }
+    // ---- exact tasks' flags: (lane, stream bit, task), dealt to the threads one by one: a wave runs the body about once, not
+    // as often as its unluckiest lane has flags
+    for (u32 idx = tid; idx < n_flags; idx += (u32)NTH) {
+        const u32 f = flags[idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
+        // (a clean tile's first stream looks at positions in front of the tile, where N is possible and nothing says so
+        // in the window: general routine, later)
+        if ((frl | fbit) || xw) win_verify_flag(tc, wc, frl, fbit, k);
+        else defer(tc, tc.tile_base, k, 0u, 1u, 0u, 0ull);
     }
     PRF_VSTAMP(14);
     // ---- group-task records: the upper half of the workgroup, alternating between its two waves (a wave's pass costs the
@@ -586,7 +636,7 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_ld
                 word &= word - 1;
                 const u32 sq = (bit * 64u + rl) * T;
                 if (sq >= 32u || xw) win_verify_group(tc, wc, WIN_LEAD + sq, k, 1u << (sc - 1u));
-                else verify_stream(tc.tile_base + sq, k, sc);
+                else defer(tc, tc.tile_base, k, sc, 1u, 0u, 0ull);
             }
         }
     } else {
@@ -596,7 +646,31 @@ __device__ __forceinline__ u32 verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_ld
             boundary_item(tc, wc, it & 0xFFFFu, it >> 16);
         }
     }
-    return n_flags;
+}
+
+// A tile with more deferred candidates than their list holds: everything again, by the general routine alone (the rows the
+// first attempt listed have been dropped by the caller).  Cold code: not inlined.
+__device__ __noinline__ void verify_general(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems,
+                                            const unsigned short __attribute__((address_space(3))) *flags, u32 n_flags, u32 tid) {
+    const TileCtx &tc = *reinterpret_cast<const TileCtx *>(prf_smem);
+    for (u32 idx = tid; idx < n_flags; idx += (u32)NTH) {
+        const u32 f = flags[idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
+        verify_stream(tc.tile_base + (u64)(fbit * 64u + frl) * T, k, 0u);
+    }
+    for (u32 idx = tid; idx < n_recs; idx += (u32)NTH) {
+        const u64 rec = recs[idx];
+        const u32 rl = (u32)rec & 63u, k = ((u32)rec >> 6) & 511u, sc = ((u32)rec >> 15) & 3u;
+        u32 word = (u32)(rec >> 17);
+        while (word) {
+            const u32 bit = (u32)__builtin_ctz(word);
+            word &= word - 1;
+            verify_stream(tc.tile_base + (u64)(bit * 64u + rl) * T, k, sc);
+        }
+    }
+    for (u32 idx = tid; idx < n_bitems; idx += (u32)NTH) {
+        const u32 it = bitems[idx];
+        boundary_general(tc, it & 0xFFFFu, it >> 16);
+    }
 }
 
 // The tasks' answers -> LDS lists.  Every lane of the wave calls these together.
@@ -605,28 +679,30 @@ struct Emit {
     prf_lds_u32 *cnt;        // this tile's counter set
     int lane;
 
-    // Exact tasks: the lanes' words of ONE task -> the task's list of flags (lane | stream bit << 6), ballot-compacted; the
-    // count goes behind the lists.  A task with more flags than its list holds (a tile of long runs) verifies the surplus on
-    // the spot with the general routine.
-    __device__ __forceinline__ void push_flags(u32 word, u32 e, u32 k, prf_lds_u32 *hotw, u32 n_exact) {
+    // Exact tasks: the lanes' words of ONE task -> flags (lane | stream bit << 6 | task << 11) appended to the tile's list,
+    // ballot-compacted, one LDS atomic per round (a round takes one flag of every lane that has any left).  Flags beyond the
+    // list's capacity (a tile of long runs) are verified on the spot with the general routine.
+    __device__ __forceinline__ void push_flags(u32 word, u32 e, u32 k, prf_lds_u32 *flag_words) {
         typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
-        prf_lds_u16 *list = (prf_lds_u16 *)hotw + e * FLAGS_PER_TASK;
-        u32 n = 0;  // wave-uniform
+        prf_lds_u16 *list = (prf_lds_u16 *)flag_words;
         for (;;) {
             const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
             if (bal == 0) break;
+            const int first = (int)__builtin_ctzll(bal);
+            u32 base = 0;
+            if (lane == first) base = atomicAdd((u32 *)(cnt + CNT_FLAGS), (u32)__builtin_popcountll(bal));
+            base = (u32)__builtin_amdgcn_readlane((int)base, first);
             if (word) {
                 const u32 bit = (u32)__builtin_ctz(word);
                 word &= word - 1;
-                const u32 at = n + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
-                if (at < FLAGS_PER_TASK) list[at] = (unsigned short)((u32)lane | (bit << 6));
-                else verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u);
+                const u32 at = base + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                if (at < (u32)FLAG_CAP) {
+                    list[at] = (unsigned short)((u32)lane | (bit << 6) | (e << 11));
+                } else {
+                    atomicAdd((u32 *)(cnt + CNT_EARLY), 1u);
+                    verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u);
+                }
             }
-            n += (u32)__builtin_popcountll(bal);
-        }
-        if (lane == 0) {
-            hotw[n_exact * 64u + e] = n < FLAGS_PER_TASK ? n : FLAGS_PER_TASK;
-            if (n > FLAGS_PER_TASK) atomicAdd((u32 *)(cnt + CNT_EARLY), n - FLAGS_PER_TASK);
         }
     }
 
@@ -759,25 +835,28 @@ __device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, int lane, u32 k0, 
     });
 }
 
-// candidate word of row t: rows t .. t+M-1 all match and row t-1 does not (`before` = mismatch word of row t-1).
-// m is indexed by row+1 (m[0] = the row before the stream), o3[t] = OR of rows t..t+2.
+// OR of the mismatch words of the M rows t .. t+M-1.  mm is indexed by row + 1 (mm[0] = the row before the stream),
+// o3[i] = mm[i] | mm[i+1] | mm[i+2] (the rows i-1 .. i+1).
 template <int M, int t, int LM, int LO>
-__device__ __forceinline__ u32 start_word(const u32 (&m)[LM], const u32 (&o3)[LO], u32 before) {
-    if constexpr (M == 1) return ~m[t + 1] & before;
-    else if constexpr (M == 2) return nor_and(m[t + 1], m[t + 2], before);
-    else if constexpr (M == 3) return ~o3[t] & before;
-    else if constexpr (M <= 6) return nor_and(o3[t], o3[t + M - 3], before);
-    else if constexpr (M <= 9) return ~or3(o3[t], o3[t + 3], o3[t + M - 3]) & before;
-    else if constexpr (M <= 12) return nor_and(or3(o3[t], o3[t + 3], o3[t + 6]), o3[t + M - 3], before);
-    else return ~or3(or3(o3[t], o3[t + 3], o3[t + 6]), o3[t + 9], o3[t + M - 3]) & before;
+__device__ __forceinline__ u32 window_or(const u32 (&mm)[LM], const u32 (&o3)[LO]) {
+    constexpr int j = t + 1;  // first index
+    if constexpr (M == 1) return mm[j];
+    else if constexpr (M == 2) return mm[j] | mm[j + 1];
+    else if constexpr (M == 3) return o3[j];
+    else if constexpr (M <= 6) return o3[j] | o3[j + M - 3];
+    else if constexpr (M <= 9) return or3(o3[j], o3[j + 3], o3[j + M - 3]);
+    else if constexpr (M <= 12) return or3(o3[j], o3[j + 3], o3[j + 6]) | o3[j + M - 3];
+    else return or3(or3(o3[j], o3[j + 3], o3[j + 6]), o3[j + 9], o3[j + M - 3]);
 }
 
 // ---- exact task: motif size K whose minimum run length is M < 15; the whole stream in one straight-line block ----
-// Returns the lane's word: bit b set = stream (lane, b) holds a row t in 0..31 that starts a run of >= M matches.
+// Returns the lane's word: bit b set = stream (lane, b) holds a row t in 0..31 that starts a run of >= M matches:
+// rows t .. t+M-1 all match and row t-1 does not, i.e. the window of M rows at t matches and the window at t-1 does not.
 // The rows 0 .. 31+M-1+K of the extended stream are read ONCE, slot by slot (4 rows of both planes); a mismatch word is
-// computed as soon as its partner row (K further on) is there, a start word as soon as its M rows are: the compiler sees
-// straight-line code in that order and keeps the live window -- K + 4 rows, M + 1 mismatch words, M - 2 triple ORs -- in
-// registers (round 2 read all 60 rows first: 128 VGPRs, four workgroups per CU).
+// computed as soon as its partner row (K further on) is there, a window as soon as its last row is: the compiler sees
+// straight-line code in that order and keeps only what is live -- K + 4 rows of two planes, M - 2 triple ORs, three
+// mismatch words, the previous window -- under the 56 registers a function may use without saving any for its caller
+// (round 2 read all 60 rows first: 128 VGPRs, four workgroups per CU).
 // relax (mixed tile): a stream whose first M rows all match counts as well -- together with the starts that is "some M
 // matching rows begin in this stream", which no added match (a not-ACGT position reads as A) can take away.
 // Not inlined: one compact function per (K, M), called by the one wave that runs the task.
@@ -788,19 +867,10 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
     constexpr int NG = (NM + K + 3) / 4;     // 16-byte slots of rows read
     static_assert(4 * NG <= 2 * T, "an exact task reads its own lane and the next one");
     prf_lds_cu4 *lane_base = vimg + lane;
-    // Row -1 of stream (lane, b) is row T-1 of stream (lane-1, b); for lane 0 it is row T-1 of stream (63, b-1):
-    // lane 63's word one bit up, with bit 0 (the previous tile's last stream) unknown -> "mismatch", verification decides.
-    const int pl = (lane + 63) & 63;
-    prf_lds_cu4 *pp = vimg + pl + (RG - 1) * NC;
-    u32 p0 = pp[0].w, p1 = pp[PS].w;
-    if (lane == 0) {
-        p0 <<= 1;
-        p1 <<= 1;
-    }
     u32 r0[4 * NG], r1[4 * NG];
-    u32 m[NM + 1];
-    u32 o3[NM];
-    u32 hot = 0;
+    u32 mm[NM + 1];
+    u32 o3[NM + 1];
+    u32 hot = 0, prev = 0;  // prev: the window one row earlier
     static_for<0, NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
@@ -810,17 +880,34 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
         static_for<0, 4>([&](auto jc) {
             constexpr int i = 4 * g + decltype(jc)::value - K;  // the mismatch row whose partner row has just arrived
             if constexpr (i == -1) {
-                m[0] = or_xor(p0 ^ r0[K - 1], p1, r1[K - 1]);
-                if (lane == 0) m[0] |= 1u;
+                // Row -1 of stream (lane, b) is row T-1 of stream (lane-1, b); for lane 0 it is row T-1 of stream (63, b-1):
+                // lane 63's word one bit up, with bit 0 (the previous tile's last stream) unknown -> "mismatch", verification
+                // decides.
+                const int pl = (lane + 63) & 63;
+                prf_lds_cu4 *pp = vimg + pl + (RG - 1) * NC;
+                u32 p0 = pp[0].w, p1 = pp[PS].w;
+                if (lane == 0) {
+                    p0 <<= 1;
+                    p1 <<= 1;
+                }
+                mm[0] = or_xor(p0 ^ r0[K - 1], p1, r1[K - 1]);
+                if (lane == 0) mm[0] |= 1u;
+                if constexpr (M == 1) prev = mm[0];  // (the window of one row at t = -1)
             } else if constexpr (i >= 0 && i < NM) {
-                m[i + 1] = or_xor(r0[i] ^ r0[i + K], r1[i], r1[i + K]);
-                if constexpr (M >= 3 && i >= 2) o3[i - 2] = or3(m[i - 1], m[i], m[i + 1]);
-                constexpr int t = i - (M - 1);  // the start word whose last row this is
-                if constexpr (t >= 0 && t < T) hot |= start_word<M, t>(m, o3, m[t]);
+                mm[i + 1] = or_xor(r0[i] ^ r0[i + K], r1[i], r1[i + K]);
+                if constexpr (M >= 3 && i >= 1) o3[i - 1] = or3(mm[i - 1], mm[i], mm[i + 1]);
+                constexpr int t = i - (M - 1);  // the window whose last row this is
+                if constexpr (t >= -1 && t < T) {
+                    const u32 win = window_or<M, t>(mm, o3);
+                    if constexpr (t >= 0) hot = bitop3<(TA | (~TB & TC)) & 0xFF>(hot, win, prev);  // hot | (~win & prev)
+                    if constexpr (t == 0) {
+                        if (relax) hot |= ~win;
+                    }
+                    prev = win;
+                }
             }
         });
     });
-    if (relax) hot |= start_word<M, 0>(m, o3, ~0u);
     return hot;
 }
 
@@ -875,9 +962,9 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, 
             const u32 word = exact_any<NC>(vimg, lane, relax, task.k0, task.kind);
             asm volatile("" ::"v"(word));
             t_call += __builtin_amdgcn_s_memtime() - tc0;
-            em.push_flags(word & allow, task.item0, task.k0, hotw, plan.n_exact);
+            em.push_flags(word & allow, task.item0, task.k0, hotw);
 #else
-            em.push_flags(exact_any<NC>(vimg, lane, relax, task.k0, task.kind) & allow, task.item0, task.k0, hotw, plan.n_exact);
+            em.push_flags(exact_any<NC>(vimg, lane, relax, task.k0, task.kind) & allow, task.item0, task.k0, hotw);
 #endif
         }
     }
@@ -973,16 +1060,19 @@ struct NextRegs {
 template <int NC>
 __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     constexpr u32 R1_OFF = (u32)SMEM_HDR, R1_BYTES = (u32)(2 * RG * NC * 16);
-    constexpr u32 RECS_OFF = R1_OFF + R1_BYTES, KEYS_OFF = RECS_OFF + (u32)REC_CAP * 8u, ALLOW_OFF = KEYS_OFF + 2u * (u32)ROW_CAP_LDS * 4u,
-                  HOTW_OFF = ALLOW_OFF + 256u;
+    // (the deferred candidates' list is written while the candidates are verified, the mask of the all-N streams of a mixed tile
+    // is read before its scan: they share 512 bytes)
+    constexpr u32 RECS_OFF = R1_OFF + R1_BYTES, KEYS_OFF = RECS_OFF + (u32)REC_CAP * 8u, SLOW_OFF = KEYS_OFF + 2u * (u32)ROW_CAP_LDS * 4u,
+                  HOTW_OFF = SLOW_OFF + (u32)SLOW_CAP * 16u, BITEMS_OFF = HOTW_OFF + (u32)FLAG_CAP * 2u;
+    static_assert(SLOW_CAP * 16 >= 256, "the all-N stream masks lie in the deferred candidates' list");
     static_assert(2 * LW * 8 <= (int)R1_BYTES, "the window of the linear planes must fit the image's region");
     static_assert((2 * LW / 2 + 63) / 64 <= 5 * MAX_WAVES, "window pieces per wave");
     prf_lds_u4 *vimg = (prf_lds_u4 *)(prf_smem + R1_OFF);
     prf_lds_u64 *recs = (prf_lds_u64 *)(prf_smem + RECS_OFF);
     prf_lds_u32 *keys = (prf_lds_u32 *)(prf_smem + KEYS_OFF);
-    prf_lds_u32 *nostart = (prf_lds_u32 *)(prf_smem + ALLOW_OFF);
-    prf_lds_u32 *hotw = (prf_lds_u32 *)(prf_smem + HOTW_OFF);  // exact tasks: flag lists (256 B per task), then 16 counts
-    prf_lds_u32 *bitems = hotw + g.plan.n_exact * 64u + 16u;    // boundary items, plan.n_group_k of them
+    prf_lds_u32 *nostart = (prf_lds_u32 *)(prf_smem + SLOW_OFF);
+    prf_lds_u32 *hotw = (prf_lds_u32 *)(prf_smem + HOTW_OFF);      // exact tasks: the tile's list of (stream, task) flags, 2 bytes each
+    prf_lds_u32 *bitems = (prf_lds_u32 *)(prf_smem + BITEMS_OFF);  // boundary items, plan.n_group_k of them
 
     const int tid0 = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -1014,10 +1104,9 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
         tcw->min_span = g.min_span;
         tcw->lin_off = R1_OFF;
         tcw->keys_off = KEYS_OFF;
-        tcw->hotw_off = HOTW_OFF;
-        tcw->n_exact = g.plan.n_exact;
+        tcw->slow_off = SLOW_OFF;
         tcw->k_exact0 = g.plan.k_exact0;
-        tcw->cof_off = HOTW_OFF + 4u * (g.plan.n_exact * 64u + 16u + g.plan.n_group_k);
+        tcw->cof_off = BITEMS_OFF + 4u * g.plan.n_group_k;
     }
 
     // Launch slots are handed out dynamically (tiles differ in cost by a factor of three; a fixed stride leaves the last
@@ -1058,7 +1147,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             static_for<1, RG>([&](auto rc) { a &= v[decltype(rc)::value]; });
             nostart[tid] = a.x & a.y & a.z & a.w;
         }
-        if (tid < 4) cnt[tid] = 0;  // rows, records, early verifications, long rows (the other set is still read by slow waves)
+        if (tid < 8) cnt[tid] = 0;  // rows, records, flags, ... (the other set is still read by slow waves)
         if (tid == 0) {  // the tile's part of the context (the rest was written once, above)
             TileCtx *tcw = reinterpret_cast<TileCtx *>(prf_smem);
             tcw->w0 = tile * PRF_TILE_WORDS - LIN_PRE;
@@ -1067,7 +1156,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             tcw->slab = (prf_glb_u64 *)(g.slabs + (u64)slot * g.slab_cap);
             tcw->tile_base = tile * PRF_TILE;
             tcw->has_lin = 0u;
-            tcw->cnt_off = (u32)HDR_CNT + 16u * parity;
+            tcw->cnt_off = (u32)HDR_CNT + 32u * parity;
         }
     }
     PRF_STAMP(1);
@@ -1118,7 +1207,11 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
         const u32 n0 = cnt[CNT_ROWS];
         for (u32 i = (u32)tid; i < (u32)ROW_CAP_LDS; i += (u32)NTH)
             if (i >= n0) keys[i] = 0xFFFFFFFFu;
-        if (tid == 0) reinterpret_cast<TileCtx *>(prf_smem)->has_lin = 1u;
+        if (tid == 0) {
+            reinterpret_cast<TileCtx *>(prf_smem)->has_lin = 1u;
+            cnt[CNT_ROWS0] = n0;
+            cnt[CNT_LONG0] = cnt[CNT_LONG];
+        }
     }
     __syncthreads();  // (waits for the window's DMA too)
     PRF_STAMP(4);
@@ -1126,16 +1219,19 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     // ---- 3b. verify, all waves together: every candidate -> a row in the tile's list, or nothing ----
     // (the record waves are the critical path of this phase, the flag waves wait for them at the barrier below)
     set_prio(wave < MAX_WAVES / 2 ? (g.plan.prio >> 6) & 3u : (g.plan.prio >> 8) & 3u);
+    const u32 *xw = hasx ? reinterpret_cast<const u32 *>(g.X + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE)) : nullptr;
+    typedef const unsigned short __attribute__((address_space(3))) prf_lds_cu16;
+    u32 n_recs = cnt[CNT_RECS], n_flags = cnt[CNT_FLAGS];
     {
-        const u32 nr = cnt[CNT_RECS];
-        const u32 *xw = hasx ? reinterpret_cast<const u32 *>(g.X + ((long long)(tile * PRF_TILE_WORDS) - LIN_PRE)) : nullptr;
-        u32 n_flags = verify_all((prf_lds_cu64 *)recs, nr < (u32)REC_CAP ? nr : (u32)REC_CAP, (prf_lds_cu32 *)bitems, g.plan.n_group_k, xw, (u32)tid, task_dbg);
         if (tid == 0) {
-            // statistics: candidates looked at = (stream, exact task) flags (thread 0 holds their number) + group-task records
-            n_flags += nr + cnt[CNT_EARLY];
-            if (n_flags)
-                atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_flags);
+            // statistics: candidates looked at = (stream, exact task) flags + group-task records (+ those verified on the spot)
+            const u32 n_cand = n_flags + n_recs + cnt[CNT_EARLY];
+            if (n_cand)
+                atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_cand);
         }
+        n_recs = n_recs < (u32)REC_CAP ? n_recs : (u32)REC_CAP;
+        n_flags = n_flags < (u32)FLAG_CAP ? n_flags : (u32)FLAG_CAP;
+        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
     }
     set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
@@ -1144,7 +1240,29 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
         next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
     }
     PRF_STAMP(5);
-    __syncthreads();  // the window is dead from here on
+    __syncthreads();
+    {
+        // the candidates that could not be finished inside the window (rare: wave-uniform, read behind the barrier)
+        const u32 n_slow = (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_SLOW]);
+        if (n_slow) {
+            if (n_slow <= (u32)SLOW_CAP) {
+                if ((u32)tid < n_slow) {
+                    prf_lds_u64 *slow = (prf_lds_u64 *)(prf_smem + SLOW_OFF);
+                    slow_item(slow[2u * (u32)tid], slow[2u * (u32)tid + 1u]);
+                }
+            } else {
+                // more than the list holds: the tile's rows so far are dropped, the general routine does everything again
+                if (tid == 0) {
+                    cnt[CNT_ROWS] = cnt[CNT_ROWS0];
+                    cnt[CNT_LONG] = cnt[CNT_LONG0];
+                }
+                __syncthreads();
+                verify_general((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, (u32)tid);
+            }
+            __syncthreads();
+        }
+    }
+    // the window is dead from here on
     PRF_STAMP(6);
     const u64 nw = *(prf_lds_u64 *)next_words;  // (one read)
     slot_next = (u32)__builtin_amdgcn_readfirstlane((int)(u32)nw);
@@ -1274,6 +1392,7 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     __shared__ u64 cbase[PRF_GATHER_SLOTS_MAX];      // first position of its contig
     __shared__ u32 contig[PRF_GATHER_SLOTS_MAX];
     __shared__ u64 ticket_lds;
+    __shared__ u64 stage[3 * 256];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) .. 64
     const u32 first = blockIdx.x << g.gather_shift;
@@ -1307,44 +1426,34 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     const u32 n_mine = offs[n_slots];
     // rows beyond the capacity stay behind: the host sees the total beyond the capacity, grows the array, rescans
     const u64 room_rows = base0 < g.rows_cap ? g.rows_cap - base0 : 0;
-    const u32 n_copy = 3u * ((u64)n_mine < room_rows ? n_mine : (u32)room_rows);  // words
+    const u32 n_copy = (u64)n_mine < room_rows ? n_mine : (u32)room_rows;  // rows
     u64 *dst = reinterpret_cast<u64 *>(g.rows + base0);
-    for (u32 w0 = tid; w0 < n_copy; w0 += 1024u) {
-        u64 sr[4];
-        u32 sl[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 w = w0 + 256u * (u32)j;
-            sr[j] = 0;
-            sl[j] = 0;
-            if (w < n_copy) {
-                const u32 row = w / 3u;
-                u32 lo = 0, hi = n_slots;  // the slot that holds the row: offs[lo] <= row < offs[lo + 1]
-                while (hi - lo > 1) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (offs[mid] <= row) lo = mid; else hi = mid;
-                }
-                sl[j] = lo;
-                sr[j] = g.slabs[(u64)(first + lo) * g.slab_cap + (row - offs[lo])];
+    // 256 rows per round: thread t decodes row r0 + t into three words in LDS, then the 768 words leave as coalesced stores
+    for (u32 r0 = 0; r0 < n_copy; r0 += 256u) {
+        const u32 row = r0 + tid;
+        if (row < n_copy) {
+            u32 lo = 0, hi = n_slots;  // the slot that holds the row: offs[lo] <= row < offs[lo + 1]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (offs[mid] <= row) lo = mid; else hi = mid;
             }
+            const u64 sr = g.slabs[(u64)(first + lo) * g.slab_cap + (row - offs[lo])];
+            const u32 key = (u32)sr, kv = (u32)(sr >> 32);
+            const u64 start = tbase[lo] + (key >> 16);
+            const u32 li = kv >> 16;  // 1 + index of the true end of a row whose span is clipped
+            const u64 end = li ? g.long_ends[(u64)(first + lo) * PRF_LONG_PER_TILE + (li - 1u)] : start + (key & 0xFFFFu);
+            stage[3u * tid] = start - cbase[lo];
+            stage[3u * tid + 1u] = end - cbase[lo];
+            stage[3u * tid + 2u] = (u64)(kv & 0xFFFFu) | ((u64)contig[lo] << 32);
         }
+        __syncthreads();
+        const u32 n_words = 3u * (n_copy - r0 < 256u ? n_copy - r0 : 256u);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 w = w0 + 256u * (u32)j;
-            if (w < n_copy) {
-                const u32 which = w % 3u, key = (u32)sr[j], kv = (u32)(sr[j] >> 32), lo = sl[j];
-                const u64 start = tbase[lo] + (key >> 16);
-                u64 v;
-                if (which == 0) v = start - cbase[lo];
-                else if (which == 2) v = (u64)(kv & 0xFFFFu) | ((u64)contig[lo] << 32);
-                else {
-                    const u32 li = kv >> 16;  // 1 + index of the true end of a row whose span is clipped
-                    const u64 end = li ? g.long_ends[(u64)(first + lo) * PRF_LONG_PER_TILE + (li - 1u)] : start + (key & 0xFFFFu);
-                    v = end - cbase[lo];
-                }
-                dst[w] = v;
-            }
+        for (u32 j = 0; j < 3u; j++) {
+            const u32 w = tid + 256u * j;
+            if (w < n_words) dst[3ull * r0 + w] = stage[w];
         }
+        __syncthreads();
     }
     // the workgroup of the last slots knows the total
     if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_mine);
@@ -1466,9 +1575,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = (unsigned char)M;  // M >= 1 because min_repeats >= 2
             it.t.valid = 1;
             it.t.stride = 1;
-            // measured (stamps build, 4 workgroups per CU, units of 8.5 cycles): 2.8 k cycles for M = 6 (one operation per start
-            // word), 4.0 - 4.4 k for M = 7 .. 14 (two)
-            it.cost = M <= 6 ? 250u + 13u * (u32)M : 440u + 5u * (u32)M;
+            // measured (stamps build, 6 workgroups per CU, units of 10 cycles): 4.9 k cycles for M <= 6 (one operation per
+            // window), 5.4 k for M = 7 .. 9 (two), 6.0 k from M = 10 on (more rows of the next lane)
+            it.cost = M <= 6 ? 490u : (M <= 9 ? 545u : 600u);
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
@@ -1489,8 +1598,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            // measured: 6.3 k / 4.2 k / 3.9 k cycles with 8 sizes, 2.4 k for stride 4 with 3
-            it.cost = (stride == 1 ? 500u : (stride == 2 ? 260u : 200u)) + 30u * (u32)__builtin_popcount(valid);
+            // measured: 10.5 k / 5.1 k / 4.2 k cycles with 8 sizes, 2.2 k for stride 4 with 3
+            it.cost = stride == 1 ? 250u + 100u * (u32)__builtin_popcount(valid)
+                                  : (stride == 2 ? 110u + 50u * (u32)__builtin_popcount(valid) : 100u + 40u * (u32)__builtin_popcount(valid));
             items.push_back(it);
             reach = std::max<u32>(reach, 24 + k0 + 15);
             covered_to = k0 + 8;
@@ -1508,7 +1618,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     // a wave without tasks, if there is one.  (Tried and dropped: the waves of a workgroup pulling tasks from one list
     // through an LDS counter at run time -- every wave's scan got 2-3 k cycles longer; the stride-1 group task cut in two
     // halves of four sizes -- a half costs three quarters of the whole, its four blocks are LDS latency, not arithmetic.)
-    constexpr u32 TICKET_COST = 350;
+    constexpr u32 TICKET_COST = 300;
     bool ticket_dealt = nw < (u32)PRF_VMAX_WAVES;
     plan->ticket_wave = nw < (u32)PRF_VMAX_WAVES ? nw : 0;
     for (const Item &it : sorted) {
@@ -1521,7 +1631,41 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
         bins[w].push_back(it);
         load[w] += it.cost;
     }
-    if (!ticket_dealt) plan->ticket_wave = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+    if (!ticket_dealt) {
+        plan->ticket_wave = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[plan->ticket_wave] += TICKET_COST;
+    }
+    // local improvement of the greedy deal: while the busiest wave can hand a task to, or swap a task with, another wave so that
+    // the larger of the two loads drops, do it (a dozen tasks: the default plan goes from 1980 to 1895 units of 10 cycles)
+    for (int round = 0; round < 64; round++) {
+        const u32 hi = (u32)(std::max_element(load.begin(), load.end()) - load.begin());
+        bool moved = false;
+        for (u32 o = 0; o < nw && !moved; o++) {
+            if (o == hi) continue;
+            for (size_t i = 0; i < bins[hi].size() && !moved; i++) {
+                const u32 ci = bins[hi][i].cost;
+                if (std::max(load[hi] - ci, load[o] + ci) < load[hi]) {  // move
+                    bins[o].push_back(bins[hi][i]);
+                    bins[hi].erase(bins[hi].begin() + (long)i);
+                    load[hi] -= ci;
+                    load[o] += ci;
+                    moved = true;
+                    break;
+                }
+                for (size_t j = 0; j < bins[o].size(); j++) {
+                    const u32 cj = bins[o][j].cost;
+                    if (cj < ci && std::max(load[hi] - ci + cj, load[o] + ci - cj) < load[hi]) {  // swap
+                        std::swap(bins[hi][i], bins[o][j]);
+                        load[hi] = load[hi] - ci + cj;
+                        load[o] = load[o] + ci - cj;
+                        moved = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (!moved) break;
+    }
     {
         // default: the short, latency-bound phases (stage, the record waves of the verify phase, rows) at priority 2, the scan
         // (long, plenty of independent arithmetic) and the flag waves (they wait at the barrier anyway) at 0.  Measured on
@@ -1571,8 +1715,8 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     plan->cof_words = (kmax + 1 + 3) & ~3u;  // <= PRF_VMAX_K + 4: the table is declared with that many entries
     // header, R1 (image / window), records, row list, all-N masks, flag lists + counts, boundary items, cofactor table
     plan->lds_bytes = (u32)(SMEM_HDR + (size_t)2 * RG * plan->nc * sizeof(uint4) + (size_t)REC_CAP * sizeof(u64) +
-                            (size_t)2 * ROW_CAP_LDS * sizeof(u32) + 256 + (size_t)(plan->n_exact * 64 + 16 + plan->n_group_k) * sizeof(u32) +
-                            (size_t)plan->cof_words * sizeof(u32));
+                            (size_t)2 * ROW_CAP_LDS * sizeof(u32) + (size_t)SLOW_CAP * 16 + (size_t)FLAG_CAP * 2 +
+                            (size_t)plan->n_group_k * sizeof(u32) + (size_t)plan->cof_words * sizeof(u32));
     plan->per_cu = 0;  // (set at the first launch: the occupancy the runtime reports for this much LDS)
     return need_nc <= 80;
 }
