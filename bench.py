@@ -398,6 +398,7 @@ def main():
                          "traffic": pmc_traffic(args.workload, args.kmin, args.kmax) if (st0.path == 1 and world == 1) else None,
                          "kernel": "prf_vscan_kernel (fused scan + verify + per-tile sorted rows)" if st0.path == 1 else "prf_scan_generic_kernel",
                          "kernel_ms": round(p1, 5),
+                         "kernel_ms_min_median": [round(float(np.min(scan_ms)), 5), round(float(np.median(scan_ms)), 5)] if scan_ms is not None else None,
                          "gather_kernel_ms": round(float(np.mean(gather_kernel_ms)), 5) if gather_kernel_ms else None,
                          "algorithmic_bytes_per_launch": bytes_alg,
                          # the same counting only the tiles that are launched (tiles of nothing but N are skipped)

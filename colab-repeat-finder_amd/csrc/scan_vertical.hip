@@ -613,19 +613,11 @@ __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_l
     wc.win0 = tc.tile_base - WIN_LEAD;
     wc.min_repeats = tc.min_repeats;
     wc.min_span = tc.min_span;
-    // ---- exact tasks' flags: (lane, stream bit, task), dealt to the threads one by one: a wave runs the body about once, not
-    // as often as its unluckiest lane has flags
-    for (u32 idx = tid; idx < n_flags; idx += (u32)NTH) {
-        const u32 f = flags[idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
-        // (a clean tile's first stream looks at positions in front of the tile, where N is possible and nothing says so
-        // in the window: general routine, later)
-        if ((frl | fbit) || xw) win_verify_flag(tc, wc, frl, fbit, k);
-        else defer(tc, tc.tile_base, k, 0u, 1u, 0u, 0ull);
-    }
-    PRF_VSTAMP(14);
-    // ---- group-task records: the upper half of the workgroup, alternating between its two waves (a wave's pass costs the
-    // same with 1 or 64 records; the flags keep the lower waves busy meanwhile)
+    // The two halves of the workgroup run different code side by side: a pass over the group-task records (upper half) takes
+    // about as long as two passes over the flags plus one over the boundary items (lower half); a wave's pass costs the same
+    // with 1 or 64 candidates.
     if (tid >= (u32)NTH / 2u) {
+        // ---- group-task records, alternating between the two waves
         const u32 up = (u32)NTH - 1u - tid;  // 0 .. 127: thread 255, 254, ...
         for (u32 idx = 2u * (up & 63u) + (up >> 6); idx < n_recs; idx += (u32)NTH / 2u) {
             const u64 rec = recs[idx];
@@ -640,7 +632,17 @@ __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_l
             }
         }
     } else {
-        // ---- boundary items: the lower half, from its last thread down (the flags fill it from the first thread up)
+        // ---- exact tasks' flags: (lane, stream bit, task), dealt to the threads one by one: a wave runs the body once per 64
+        // flags, not as often as its unluckiest lane has flags
+        for (u32 idx = tid; idx < n_flags; idx += (u32)NTH / 2u) {
+            const u32 f = flags[idx], frl = f & 63u, fbit = (f >> 6) & 31u, k = tc.k_exact0 + (f >> 11);
+            // (a clean tile's first stream looks at positions in front of the tile, where N is possible and nothing says so
+            // in the window: general routine, later)
+            if ((frl | fbit) || xw) win_verify_flag(tc, wc, frl, fbit, k);
+            else defer(tc, tc.tile_base, k, 0u, 1u, 0u, 0ull);
+        }
+        PRF_VSTAMP(14);
+        // ---- boundary items: from the half's last thread down (the last round of flags fills it from the first thread up)
         for (u32 idx = (u32)NTH / 2u - 1u - tid; idx < n_bitems; idx += (u32)NTH / 2u) {
             const u32 it = bitems[idx];
             boundary_item(tc, wc, it & 0xFFFFu, it >> 16);
