@@ -529,7 +529,7 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
     a.slabs = c->d_slabs; a.long_ends = c->d_long_ends; a.slab_count = c->d_slab_count; a.block_sum = c->d_block_sum; a.slab_cap = c->slab_cap;
     // the gather takes 8 launch slots per workgroup on small launches (more workgroups in flight), 64 on large ones
-    a.gather_shift = lv.n <= 8192u ? 3u : 4u;
+    a.gather_shift = lv.n <= 8192u ? 3u : 5u;
     {   // PRF_GATHER_SHIFT (diagnostic): launch slots per gather workgroup = 1 << shift, 3 .. 6
         static const int gs_env = getenv("PRF_GATHER_SHIFT") ? atoi(getenv("PRF_GATHER_SHIFT")) : -1;
         if (gs_env >= 3 && gs_env <= 6) a.gather_shift = (u32)gs_env;

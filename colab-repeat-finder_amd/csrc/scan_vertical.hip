@@ -873,12 +873,20 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
     u32 mm[NM + 1];
     u32 o3[NM + 1];
     u32 hot = 0, prev = 0;  // prev: the window one row earlier
+    auto load_slot = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < NG) {
+            prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
+            const prf_u32x4 v0 = ps[0], v1 = ps[PS];
+            r0[4 * g] = v0.x; r0[4 * g + 1] = v0.y; r0[4 * g + 2] = v0.z; r0[4 * g + 3] = v0.w;
+            r1[4 * g] = v1.x; r1[4 * g + 1] = v1.y; r1[4 * g + 2] = v1.z; r1[4 * g + 3] = v1.w;
+        }
+    };
+    load_slot(std::integral_constant<int, 0>{});
     static_for<0, NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
-        const prf_u32x4 v0 = ps[0], v1 = ps[PS];
-        r0[4 * g] = v0.x; r0[4 * g + 1] = v0.y; r0[4 * g + 2] = v0.z; r0[4 * g + 3] = v0.w;
-        r1[4 * g] = v1.x; r1[4 * g + 1] = v1.y; r1[4 * g + 2] = v1.z; r1[4 * g + 3] = v1.w;
+        load_slot(std::integral_constant<int, g + 1>{});  // one slot ahead of the rows that are computed: its latency hides behind them
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, 4>([&](auto jc) {
             constexpr int i = 4 * g + decltype(jc)::value - K;  // the mismatch row whose partner row has just arrived
             if constexpr (i == -1) {
