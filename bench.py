@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the perfect-tandem-repeat scan on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22|chr1|random|hg38-random]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22|chr22-real|chr1|random|hg38-random]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one complete scan of the workload for every motif size in [kmin,kmax]: two back-to-back launches on one stream
@@ -139,6 +139,13 @@ def build_workload(args, ctx, synth):
         g = ctx.load([seq], args.kmax)
         desc = f"chr22-sized synthetic stand-in contig ({length} bp; hg38-like N blocks, planted repeats; synth.chr_standin)"
         return g, [length], desc, (lambda n: seq[n_head:n_head + n]), "first %d non-N bp"
+    if w == "chr22-real":
+        arr, planted = synth.chr22_real()
+        seq = arr.tobytes()
+        g = ctx.load([seq], args.kmax)
+        desc = (f"chr22 stand-in ({len(seq)} bp) with every cluster of the reference's golden chr22 BED planted at its real coordinate "
+                f"(synth.chr22_real: {len(planted)} golden rows, up to 759 rows in one 65536-position tile)")
+        return g, [len(seq)], desc, (lambda n: seq[10_510_000:10_510_000 + n]), "first %d non-N bp"
     if w == "random":
         lens = [args.length or 10_000_000_000]
         g = ctx.synth(lens, [2026], args.kmax)                     # generated in HBM, nothing crosses PCIe
@@ -158,7 +165,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["hg38", "chr22", "chr1", "random", "hg38-random"], default="hg38")
+    ap.add_argument("--workload", choices=["hg38", "chr22", "chr22-real", "chr1", "random", "hg38-random"], default="hg38")
     ap.add_argument("--length", type=int, default=0, help="contig length for chr22 / chr1 / random (default: the config's own)")
     ap.add_argument("--kmin", type=int, default=1)
     ap.add_argument("--kmax", type=int, default=0, help="default 50 (100 for --workload random: BASELINE configs[4])")
@@ -219,6 +226,8 @@ def main():
     # one untimed full scan of this rank's share: sizes the scratch buffers, gives the row count used to size the gather
     rows, st0 = scan(True)
     n_rows_local = len(rows)
+    import hashlib
+    rows_sha256 = hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest()   # pinned by tests/test_gpu_parity.py for the default workload
     my_bp = int(st0.positions)
     gather_cap = None
     if world > 1:
@@ -383,6 +392,7 @@ def main():
                        "kernel_path": "generic" if st0.path == 0 else "vertical",
                        "rows_rank0": n_rows_local, "rows_total": n_rows_total,
                        "rows_sorted_on_device": bool(st0.sorted_on_device),
+                       "rows_sha256_rank0": rows_sha256, "launches_of_the_untimed_scan": int(st0.n_launches),
                        "candidate_records_rank0": int(st0.n_candidates),
                        "steps_in_flight": 2 if pipelined else 1,
                        "multi_gpu": ({"sharding": "every rank holds the genome and scans its share of the tiles (prf_genome_select); "

@@ -87,6 +87,7 @@ struct prf_ctx {
         prf_hit_dev *rows = nullptr;
         u64 positions = 0;
         u32 tiles = 0;
+        u32 kmax = 0;
     } slot[2];
     u64 async_n = 0;
     u64 *h_async = nullptr;         // slot 1's counter block
@@ -104,6 +105,7 @@ struct prf_ctx {
     u32 stamps_n = 0;
     // where the rows of the last scan are
     u64 last_nhits = 0;
+    u32 last_kmax = 0;              // largest motif size of the last scan (the 8-byte wire rows hold 9 bits)
 };
 
 struct prf_genome {
@@ -687,7 +689,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
                 HIPCHK(hipEventElapsedTime(&ms01, ev_a, ev_b));
             }
             ms12 = 0;
-            launches = 2;
+            launches = 2u * (u32)(attempt + 1);  // (a scan that had to grow its buffers and run again shows here)
             nhits = c->h_counters[PRF_CNT_ROWS];
             sorted_on_device = c->h_counters[PRF_CNT_UNSORTED] == 0;
             ncand = 0;
@@ -791,6 +793,7 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
         if (!again) break;
     }
     c->last_nhits = nhits;
+    c->last_kmax = kmax;
     c->last_rows = c->sink ? c->sink : c->d_hits;
     c->last_sorted = sorted_on_device;
     if (stats) {
@@ -859,7 +862,7 @@ struct dev_free {
 
 // d_seq: L bytes on the device (4-byte aligned, 16 readable bytes behind them); upper: not upper-cased / validated yet
 static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats,
-                          u32 min_span, u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
+                          u32 min_span, u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches, u64 pos_offset = 0) {
     if (stop > L) stop = L;
     dev_free rows;
     u64 cap = L / 16 + 4096;
@@ -883,7 +886,7 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
             return fail(PRF_ESYMBOL,
                         "unsupported symbol at contig %u position %llu: only letters are accepted (A, C, G, T, N and -- as ordinary "
                         "symbols, like the reference -- any other letter, in either case); libprf refuses other bytes instead of guessing",
-                        contig_index, (unsigned long long)h[PRF_CNT_BADPOS]);
+                        contig_index, (unsigned long long)(h[PRF_CNT_BADPOS] + pos_offset));  // (pos_offset: the N trimmed off the front)
         if (h[PRF_CNT_CAND])
             return fail(PRF_EINDEX, "string index out of range");  // the message of Python's IndexError (tracker :87)
         const u64 n = h[PRF_CNT_HITS];
@@ -918,14 +921,14 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
 }
 
 static int literal_one(prf_ctx *c, const prf_contig &ct, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
-                       u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches) {
+                       u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches, u64 pos_offset) {
     const u64 L = ct.len;
     if (L && !ct.ascii) return fail(PRF_EINVAL, "prf_scan_literal: NULL sequence");
     if (L >= (1ull << 40)) return fail(PRF_EUNSUPPORTED, "prf_scan_literal: input too large (2^40 positions)");
     dev_free seq;
     HIPCHK(hipMalloc(&seq.p, L + 16));
     if (L) HIPCHK(hipMemcpyAsync(seq.p, ct.ascii, L, hipMemcpyHostToDevice, c->stream));
-    return literal_device(c, (uint8_t *)seq.p, L, true, contig_index, kmin, kmax, min_repeats, min_span, stop, rows_out, ms, launches);
+    return literal_device(c, (uint8_t *)seq.p, L, true, contig_index, kmin, kmax, min_repeats, min_span, stop, rows_out, ms, launches, pos_offset);
 }
 
 static int literal_finish(prf_ctx *c, std::vector<prf_hit> &rows, float ms, u32 launches, u64 positions, prf_hits *out,
@@ -1007,6 +1010,7 @@ static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, co
     if (kmax > 60000) return fail(PRF_EUNSUPPORTED, "max_motif_size %u > 60000", kmax);
     if (min_repeats > 1000000u || min_span > (1u << 30)) return fail(PRF_EINVAL, "threshold out of range");
     if (c->slot[0].seq || c->slot[1].seq) return fail(PRF_EINVAL, "prf_scan_literal: pipelined scans are in flight on this context");
+    if (c->sink) return fail(PRF_EUNSUPPORTED, "min_repeats == 1: not with a row sink (the rows of the literal lane are handed over on the host)");
     HIPCHK(hipSetDevice(c->dev));
     std::vector<prf_hit> rows;
     float ms = 0;
@@ -1026,7 +1030,7 @@ static int literal_impl(prf_ctx *c, const prf_contig *contigs, int n_contigs, co
             w.len = hi - lo;
         }
         const size_t at = rows.size();
-        const int rc = literal_one(c, w, (u32)i, kmin, kmax, min_repeats, min_span, stops ? stops[i] : w.len, rows, &ms, &launches);
+        const int rc = literal_one(c, w, (u32)i, kmin, kmax, min_repeats, min_span, stops ? stops[i] : w.len, rows, &ms, &launches, lo);
         if (rc) return rc;
         for (size_t r = at; r < rows.size(); r++) {
             rows[r].start += lo;
@@ -1119,6 +1123,7 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
     sl.seq = seq;
     sl.positions = lv.positions;
     sl.tiles = lv.n;
+    sl.kmax = kmax;
     c->async_n++;
     *seq_out = seq;
     return PRF_OK;
@@ -1146,6 +1151,7 @@ int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
     if (sl->h[PRF_CNT_HIT_OVF] > c->slab_cap || nhits > c->hit_cap || sl->h[PRF_CNT_LONG_OVF])
         return fail(PRF_EUNSUPPORTED, "prf_scan_wait: the buffers sized by the last synchronous scan overflowed; scan synchronously");
     c->last_nhits = nhits;
+    c->last_kmax = sl->kmax;
     c->last_rows = sl->rows;
     c->last_sorted = sl->h[PRF_CNT_UNSORTED] == 0;
     if (stats) {
@@ -1262,6 +1268,9 @@ int prf_last_hits_packed_to_device(prf_ctx *c, const prf_genome *g, void *dst, u
     if (!c || !g || g->ctx != c || !n_rows || !dst) return fail(PRF_EINVAL, "prf_last_hits_packed_to_device: bad arguments");
     HIPCHK(hipSetDevice(c->dev));
     *n_rows = c->last_nhits;
+    if (c->last_kmax > 511u)  // (such rows used to leave with a truncated motif size)
+        return fail(PRF_EUNSUPPORTED, "the 8-byte wire rows hold motif sizes up to 511; the last scan went up to %u -- hand its rows over whole "
+                    "(prf_last_hits_to_device)", c->last_kmax);
     if (c->last_nhits > capacity_rows)
         return fail(PRF_EINVAL, "the packed row buffer holds %llu rows, the scan found %llu", (unsigned long long)capacity_rows,
                     (unsigned long long)c->last_nhits);

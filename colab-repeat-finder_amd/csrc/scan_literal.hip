@@ -103,14 +103,14 @@ __device__ void lit_event(const uint8_t *__restrict__ s, i64 L, i64 k, i64 i0, u
 // two aligned dwords with v_alignbyte_b32.  The buffer has 16 readable bytes behind the sequence.
 __global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 n_k, u32 min_repeats,
                                                              u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
-                                                             u64 cap, u64 *__restrict__ counters) {
+                                                             u64 cap, u64 *__restrict__ counters, u64 block0) {
     // the motif size is the fast index of the grid: the workgroups resident at one time read the same stretch of the
     // sequence for all motif sizes, which L2 then serves (with the motif size as the slow index every size streamed the
     // whole sequence from HBM again: FETCH_SIZE 1.5 GB per launch for 50 MB x 50 sizes)
     const i64 k = (i64)kmin + blockIdx.x % n_k;
     const i64 Lk = L > k ? L - k : 0;            // tracker :50: the tracker never moves past len - k
     const i64 pos_f = stop < Lk ? stop : Lk;     // where it stands when done() is called
-    const i64 i_base = 4 * ((i64)(blockIdx.x / n_k) * blockDim.x + threadIdx.x);
+    const i64 i_base = 4 * ((i64)(block0 + blockIdx.x / n_k) * blockDim.x + threadIdx.x);  // (block0: a long sequence takes several launches)
     if (i_base > pos_f) return;
     u32 a = 0, b = 0;
     if (i_base < pos_f) {                        // then i_base + k < L: both dwords lie inside the buffer
@@ -278,8 +278,17 @@ hipError_t prf_launch_lit_events(hipStream_t st, const uint8_t *s, u64 L, u32 km
     const u64 n_threads = (stop < Lk ? stop : Lk) / 4 + 1;  // four positions per thread
     const u64 bx = (n_threads + 255) / 256;
     const u64 n_k = kmax - kmin + 1;
-    if (bx * n_k > 0x7fffffffull) return hipErrorInvalidValue;  // one-dimensional grid: workgroup b = (positions b / n_k, size b % n_k)
-    hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)(bx * n_k)), dim3(256), 0, st, s, (long long)L, kmin, (u32)n_k,
-                       min_repeats, min_span, (long long)stop, contig, rows, cap, counters);
-    return hipGetLastError();
+    // one-dimensional grid: workgroup b = (positions b / n_k, size b % n_k).  A grid holds fewer than 2^32 threads (2^24
+    // workgroups of 256): an hg38 chr1-sized sequence with 100 motif sizes takes two launches (it used to fail)
+    const u64 max_wg = (1ull << 24) - 1ull;
+    if (n_k > max_wg) return hipErrorInvalidValue;
+    const u64 bx_per_launch = max_wg / n_k;
+    for (u64 b0 = 0; b0 < bx; b0 += bx_per_launch) {
+        const u64 nb = bx - b0 < bx_per_launch ? bx - b0 : bx_per_launch;
+        hipLaunchKernelGGL(prf_lit_events_kernel, dim3((unsigned)(nb * n_k)), dim3(256), 0, st, s, (long long)L, kmin, (u32)n_k,
+                           min_repeats, min_span, (long long)stop, contig, rows, cap, counters, b0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }

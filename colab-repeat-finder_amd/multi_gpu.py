@@ -1,27 +1,19 @@
 """Multi-GPU sharding of the scan: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests), contigs as the unit of work, no data-path collective.
+the GPU box, "gloo" in the CPU tests), SHARES OF ONE GENOME as the unit of work, no data-path collective.
 
 The reference's only parallel strategy is file-level interval sharding in a cloud batch pipeline whose outputs
 are concatenated with `cat | sort | uniq` and repaired by merge_loci (reference
-hail_batch_pipeline/run_hail_batch_pipeline.py:76-77, :151-153, :170-175).  Here contigs are dealt to the ranks
-(longest first, to the least loaded rank), every rank scans its own contigs with its own libprf context, and the
-rows -- tiny compared with the input -- are concatenated on rank 0 with ONE padded gather.  Because per-contig
-scans are independent the result is exactly the single-GPU result; nothing has to be repaired.
+hail_batch_pipeline/run_hail_batch_pipeline.py:76-77, :151-153, :170-175).  Here every rank holds the genome and scans a
+share of it: position ranges cut at multiples of the 65536-position tile, balanced by tile cost (plan_parts).  A row
+belongs to the share that holds its first position, so the shares' row sets are disjoint, their union is exactly the
+single-GPU result and -- the shares being in genome order -- their concatenation is the sorted row array; nothing has to be
+repaired.  The rows, tiny compared with the input, reach rank 0 with ONE padded gather of 8-byte wire rows
+(pack_rows / prf_last_hits_packed_to_device -> gather_packed -> unpack_rows).  With min_repeats == 1 a sequence cannot be
+cut (plan_whole_contigs).
 """
 import numpy as np
 
 ROW_DTYPE = np.dtype([("start", "<u8"), ("end", "<u8"), ("k", "<u4"), ("contig", "<u4")])
-
-
-def plan_contig_shards(lengths, world):
-    """Longest-processing-time-first: returns, per rank, the sorted list of contig indices it scans."""
-    shards = [[] for _ in range(world)]
-    load = [0] * world
-    for idx in sorted(range(len(lengths)), key=lambda i: (-lengths[i], i)):
-        r = min(range(world), key=lambda j: (load[j], j))
-        shards[r].append(idx)
-        load[r] += lengths[idx]
-    return [sorted(s) for s in shards]
 
 
 TILE_COST = (1.0, 1.3, 0.0, 12.0)   # ordinary tile; tile with N in reach (three planes); all-N tile (never scanned); tile with a
@@ -107,39 +99,42 @@ def unpack_rows(words, capacity, side_capacity, bases, tile):
     return rows
 
 
-def rows_to_tensor(rows, capacity, torch, device):
-    """(capacity+1, 3) int64 tensor: 24-byte rows as three int64 words, the row count in the last row."""
-    t = torch.zeros((capacity + 1, 3), dtype=torch.int64, device=device)
+WIRE_K_MAX = 511   # motif sizes the 8-byte wire row holds (9 bits); larger ones are refused by the library (PRF_EUNSUPPORTED)
+
+
+def pack_rows(rows, capacity, side_capacity, bases, tile):
+    """Host reference encoder of the 8-byte wire format (what prf_pack_rows_kernel, csrc/verify.hip, writes on the device;
+    a GPU test checks the two against each other): `capacity` packed rows, one count word (rows | long rows << 40),
+    3 * side_capacity words of rows whose span does not fit 16 bits.  Returns a uint64 array."""
+    rows = np.asarray(rows, dtype=ROW_DTYPE)
     n = len(rows)
-    if n:
-        flat = np.ascontiguousarray(rows).view(np.int64).reshape(n, 3)
-        t[:n] = torch.from_numpy(flat.copy()).to(device)
-    t[capacity, 0] = n
-    return t
+    if n > capacity:
+        raise ValueError(f"the packed row buffer holds {capacity} rows, there are {n}")
+    if n and int(rows["k"].max()) > WIRE_K_MAX:
+        raise ValueError(f"motif sizes above {WIRE_K_MAX} do not fit the 8-byte wire row")
+    words = np.zeros(capacity + 1 + 3 * side_capacity, dtype=np.uint64)
+    bases = np.asarray(bases, dtype=np.uint64)
+    gpos = bases[rows["contig"]] + rows["start"]
+    span = rows["end"] - rows["start"]
+    s16 = np.minimum(span, np.uint64(65535))
+    words[:n] = ((gpos // np.uint64(tile)) << np.uint64(41)) | ((gpos % np.uint64(tile)) << np.uint64(25)) | (s16 << np.uint64(9)) \
+        | rows["k"].astype(np.uint64)
+    long_rows = rows[span >= np.uint64(65535)]
+    if len(long_rows) > side_capacity:
+        raise ValueError(f"the side list holds {side_capacity} rows, {len(long_rows)} rows are longer than 65534")
+    for j, r in enumerate(long_rows):
+        words[capacity + 1 + 3 * j: capacity + 4 + 3 * j] = (int(r["start"]), int(r["end"]), int(r["k"]) | (int(r["contig"]) << 32))
+    words[capacity] = n | (len(long_rows) << 40)
+    return words
 
 
-def tensor_to_rows(t):
-    a = t.cpu().numpy()
-    n = int(a[-1, 0])
-    return np.ascontiguousarray(a[:n]).view(ROW_DTYPE).reshape(n)
-
-
-def gather_rows(local_rows, dist, torch, device):
-    """One padded gather of every rank's rows to rank 0.  Returns the concatenated rows sorted by
-    (contig, start, end) on rank 0, None elsewhere."""
+def gather_packed(send, dist, torch, dst=0):
+    """The one collective of the data path: every rank's packed rows (an int64 tensor of the same length on every rank,
+    pack_rows' layout) gathered on rank `dst`.  Returns the list of tensors there, None elsewhere."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    cap = torch.tensor([len(local_rows)], dtype=torch.int64, device=device)
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    capacity = int(cap.item())
-    send = rows_to_tensor(local_rows, capacity, torch, device)
-    recv = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, recv, dst=0)
-    if rank != 0:
-        return None
-    parts = [tensor_to_rows(t) for t in recv]
-    rows = np.concatenate(parts) if parts else np.zeros(0, dtype=ROW_DTYPE)
-    order = np.lexsort((rows["end"], rows["start"], rows["contig"]))
-    return rows[order]
+    recv = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
+    return recv
 
 
 class ShardError(RuntimeError):
@@ -163,22 +158,3 @@ def agree_or_raise(error, dist, torch, device):
                                                              getattr(error, "code", None)))
     bad = next(i for i, m in enumerate(msgs) if m is not None)
     raise ShardError(bad, *msgs[bad])
-
-
-def scan_contigs_sharded(contigs, settings, scan_fn, dist, torch, device):
-    """contigs: list of bytes, identical on every rank.  scan_fn(list_of_bytes, settings) -> rows with
-    contig indices local to the list it was given.  Returns the rows of ALL contigs (global contig indices,
-    sorted) on rank 0, None elsewhere.  A failure of scan_fn on one rank is raised on all of them (ShardError)."""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    mine = plan_contig_shards([len(c) for c in contigs], world)[rank]
-    rows, error = np.zeros(0, dtype=ROW_DTYPE), None
-    try:
-        if mine:
-            rows = np.array(scan_fn([contigs[i] for i in mine], settings), dtype=ROW_DTYPE)
-            if len(rows):
-                rows = rows.copy()
-                rows["contig"] = np.asarray(mine, dtype=np.uint32)[rows["contig"]]
-    except Exception as exc:          # noqa: BLE001 -- whatever it is, the peers must hear about it
-        error = exc
-    agree_or_raise(error, dist, torch, device)
-    return gather_rows(rows, dist, torch, device)

@@ -7,6 +7,10 @@ standin2()         the stand-in recipe in a form that every position can compute
                    window of it on the host: uniform background, N blocks at both ends and a centromere-like gap,
                    one planted perfect tandem repeat per 588-position slot (1 700 / Mbp), motif sizes after the
                    reference's golden chr22 BED, motif = the background at the repeat's own position.
+chr22_real()       the chr22 stand-in background with EVERY cluster of the reference's golden chr22 BED planted at its real
+                   coordinate (tests/golden/chr22_clusters_all.tsv.gz, reconstructed from the BED and re-run through the
+                   reference by oracle/gen_golden.py): a workload with the real genome's row clustering -- 582 occupied
+                   65536-position tiles, up to 748 rows in one -- and 63 651 known-answer windows inside it.
 chr_standin()      (older recipe, kept for the pinned chr22 inputs) stand-in for a human chromosome: the same uniform background, N blocks where hg38 has
                    them (chr22: the first 10.51 Mb and the last 10 kb), and planted perfect tandem repeats at
                    ~1.7 k/Mbp whose motif sizes follow the reference's golden chr22 BED
@@ -161,3 +165,41 @@ def synth_codes_at(idx, seed):
     with np.errstate(over="ignore"):
         z = _splitmix(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (idx.astype(np.uint64) + np.uint64(1)) * _PHI)
     return (z >> np.uint64(62)).astype(np.uint8)
+
+
+def chr22_real(clusters_path=None, seed=22, n_head=10_510_000, n_tail=10_000, length=CHR22_LEN):
+    """-> (ASCII uint8 array of `length` bases, planted rows).  N blocks where hg38 chr22 has them, uniform background, and
+    every cluster of the golden-BED fixture written over it at its real coordinate, one flank base either side (the flanks
+    are what makes the reference reproduce exactly the cluster's rows).  planted rows: structured array (start, end, k) in
+    contig coordinates, sorted -- every one of them must be a row of the scan (the background may add rows of its own).
+    A cluster whose flank collides with its predecessor's (different base at the same position) is left out."""
+    import gzip
+    import os
+    if clusters_path is None:
+        clusters_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                     "chr22_clusters_all.tsv.gz")
+    seq = synth_bases(length, seed)
+    seq[:n_head] = ord("N")
+    seq[length - n_tail:] = ord("N")
+    rows = []
+    prev_end = -1
+    with gzip.open(clusters_path, "rt") as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            s0, body, spec = line.rstrip("\n").split("\t")
+            at = int(s0) - 1                                   # the fixture's sequence begins one flank base before the cluster
+            b = np.frombuffer(body.encode(), dtype=np.uint8)
+            if at < prev_end:                                  # shares its first base(s) with the previous cluster's flank
+                ov = prev_end - at
+                if not np.array_equal(seq[at:prev_end], b[:ov]):
+                    continue
+            if at < n_head or at + len(b) > length - n_tail:
+                continue
+            seq[at:at + len(b)] = b
+            prev_end = at + len(b)
+            for r in spec.split(","):
+                a, e, m = r.split(":")
+                rows.append((at + int(a), at + int(e), len(m)))
+    rows = np.array(sorted(rows), dtype=[("start", "<u8"), ("end", "<u8"), ("k", "<u4")])
+    return seq, rows

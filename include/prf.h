@@ -208,7 +208,8 @@ int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_ro
  * tile is the row's first position in the genome's coordinate space (contig c begins at prf_genome_contig_bases()[c]).
  * dst_device holds capacity_rows words, then ONE count word (rows | long rows << 40), then side_capacity full rows of three
  * words (start, end, k | contig << 32) for the rows whose span does not fit 16 bits.  multi_gpu.unpack_rows() decodes.
- * Fails with PRF_EINVAL if the scan found more rows than capacity_rows (or more long rows than side_capacity). */
+ * Fails with PRF_EINVAL if the scan found more rows than capacity_rows (or more long rows than side_capacity), and with
+ * PRF_EUNSUPPORTED if the last scan's max motif size exceeds 511 (k has 9 bits on the wire: hand such rows over whole). */
 int prf_last_hits_packed_to_device(prf_ctx *ctx, const prf_genome *g, void *dst_device, uint64_t capacity_rows,
                                    uint64_t side_capacity, uint64_t *n_rows);
 /* First position of every contig in the genome's coordinate space (multiples of prf_tile_positions()). */

@@ -21,6 +21,7 @@ Fixture files (all under tests/golden/):
   synth_*.json            SURVEY 8(d) synthetic sequences (by seed/length) + reference rows
   chr22_clusters.tsv.gz   known-answer clusters mined from the reference's golden BED
                           (benchmark/repeat_finder/chr22_repeats.bed), each re-run through the reference
+  chr22_clusters_all.tsv.gz  (--only clusters_all) EVERY consistent cluster of that BED with its real coordinate
 """
 import argparse
 import gzip
@@ -349,9 +350,11 @@ def gen_synth(quick):
         print(name, len(res["rows"]), "rows", round(dt, 1), "s")
 
 
-def gen_chr22_clusters(max_clusters):
+def gen_chr22_clusters(max_clusters, out_name="chr22_clusters.tsv.gz"):
     """Rows of the reference's golden BED that overlap or abut determine the sequence under
-    them; each cluster + one flank base per side is a real-genome known-answer vector."""
+    them; each cluster + one flank base per side is a real-genome known-answer vector.
+    max_clusters None: every cluster (chr22_clusters_all.tsv.gz -- the fixture synth.chr22_real() plants at the real
+    coordinates to get a workload with the real genome's row clustering)."""
     bed = os.path.join(REF, "benchmark", "repeat_finder", "chr22_repeats.bed")
     rows = []
     with open(bed) as f:
@@ -372,10 +375,10 @@ def gen_chr22_clusters(max_clusters):
     big = [c for c in clusters if len(c) >= 3]
     small = [c for c in clusters if len(c) < 3]
     rng.shuffle(small)
-    chosen = big + small[:max(0, max_clusters - len(big))]
+    chosen = clusters if max_clusters is None else big + small[:max(0, max_clusters - len(big))]
     chosen.sort(key=lambda c: c[0][0])
     n_ok = 0
-    with gzip.open(os.path.join(OUT, "chr22_clusters.tsv.gz"), "wt") as f:
+    with gzip.open(os.path.join(OUT, out_name), "wt") as f:
         f.write("#genome_start\tseq_with_1bp_flanks\trows(start:end:motif,...) relative to seq; k1-6 r3 span9; "
                 "source: reference benchmark/repeat_finder/chr22_repeats.bed\n")
         for cl in chosen:
@@ -430,6 +433,8 @@ def main():
         gen_iupac()
     if "clusters" in todo:
         gen_chr22_clusters(1500 if a.quick else 8000)
+    if "clusters_all" in todo:      # (not part of the default set: ~10 minutes of the reference)
+        gen_chr22_clusters(None, "chr22_clusters_all.tsv.gz")
     if "synth" in todo:
         gen_synth(a.quick)
 

@@ -1,6 +1,7 @@
 """CPU: the N>1 paths with world_size 2 over gloo -- genome shares (multi_gpu.plan_parts: position ranges cut at tile
-multiples, a row belongs to the share that holds its first position), the padded row gather, rank-local FASTA reading and
-part files of the command line, and the propagation of a rank-local failure.  The GPU scan is replaced by the oracle (tests
+multiples, a row belongs to the share that holds its first position), the padded gather of 8-byte wire rows (the product's
+data path: pack_rows -> gather_packed -> unpack_rows), rank-local FASTA reading and part files of the command line, and the
+propagation of a rank-local failure.  The GPU scan is replaced by the oracle (tests
 may call it), so what is checked is the sharding/gather/merge logic: the result must equal the single-process result."""
 import os
 import socket
@@ -35,7 +36,31 @@ def _oracle_scan(seqs, settings):
     return rows
 
 
+TILE = 65_536
+SIDE = 4
+
+
+def _genome():
+    """(contigs, contig bases in the library's global position space): contigs start on tile multiples behind a guard gap"""
+    contigs = _contigs() + [b"ACGT" * 10 + b"A" * 70_000 + b"C"]       # the last one: a row whose span does not fit 16 bits
+    bases, cur = [], 0
+    for c in contigs:
+        bases.append(cur)
+        cur = -(-(cur + len(c) + 20 + 64) // TILE) * TILE
+    return contigs, bases
+
+
+def _share_rows(contigs, parts, settings):
+    """what a rank's GPU scan of its share returns: the rows whose first position lies in one of the share's parts"""
+    import multi_gpu
+    rows = [r for r in _oracle_scan(contigs, settings) if any(c == r[3] and lo <= r[0] < hi for c, lo, hi in parts)]
+    return np.array(rows, dtype=multi_gpu.ROW_DTYPE)
+
+
 def _worker(rank, world, port, out_path):
+    """The product's N > 1 data path (bench.py) with the oracle in place of the GPU scan: plan_parts shares ->
+    rows of the share -> 8-byte wire rows (the host encoder, checked against the device's in a GPU test) -> ONE padded
+    gather -> decoded and concatenated on rank 0."""
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -46,37 +71,59 @@ def _worker(rank, world, port, out_path):
     import multi_gpu
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows = multi_gpu.scan_contigs_sharded(_contigs(), (1, 20, 3, 9), _oracle_scan, dist, torch, "cpu")
+        contigs, bases = _genome()
+        shares = multi_gpu.plan_parts([len(c) for c in contigs], world, TILE)
+        rows, error = np.zeros(0, dtype=multi_gpu.ROW_DTYPE), None
+        try:
+            rows = _share_rows(contigs, shares[rank], (1, 20, 3, 9))
+        except Exception as exc:                                        # noqa: BLE001
+            error = exc
+        multi_gpu.agree_or_raise(error, dist, torch, "cpu")
+        cap = torch.tensor([len(rows)], dtype=torch.int64)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        cap = int(cap.item())
+        send = torch.from_numpy(multi_gpu.pack_rows(rows, cap, SIDE, bases, TILE).view(np.int64).copy())
+        recv = multi_gpu.gather_packed(send, dist, torch)
         if rank == 0:
-            np.save(out_path, rows)
+            got = np.concatenate([multi_gpu.unpack_rows(r.numpy(), cap, SIDE, bases, TILE) for r in recv])
+            np.save(out_path, got)
         else:
-            assert rows is None
+            assert recv is None
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def test_plan_contig_shards_balances_and_covers():
-    import multi_gpu
-    lengths = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]
-    for world in (1, 2, 4, 8):
-        shards = multi_gpu.plan_contig_shards(lengths, world)
-        assert sorted(i for s in shards for i in s) == list(range(len(lengths)))
-        loads = [sum(lengths[i] for i in s) for s in shards]
-        assert max(loads) <= 1.25 * sum(lengths) / world + max(lengths) * (world > 4)
-
-
-def test_two_rank_gather_equals_single_process(tmp_path):
+def test_two_rank_gather_of_wire_rows_equals_single_process(tmp_path):
     import torch.multiprocessing as mp
     import multi_gpu
     out = str(tmp_path / "rows.npy")
     port = _free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
-    want = np.array(_oracle_scan(_contigs(), (1, 20, 3, 9)), dtype=multi_gpu.ROW_DTYPE)
+    contigs, _bases = _genome()
+    want = np.array(_oracle_scan(contigs, (1, 20, 3, 9)), dtype=multi_gpu.ROW_DTYPE)
     want = want[np.lexsort((want["end"], want["start"], want["contig"]))]
-    assert len(want) > 100
+    assert len(want) > 100 and (want["end"] - want["start"]).max() > 65_535
+    # no sort on rank 0: the shares are in genome order, their concatenation IS the sorted row array
     assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_wire_rows_round_trip_and_limits():
+    import multi_gpu
+    bases = [0, 3 * TILE]
+    rows = np.array([(5, 17, 3, 0), (TILE - 1, TILE + 20, 7, 0), (40, 70_040, 1, 1), (100, 1_123, 511, 1)], dtype=multi_gpu.ROW_DTYPE)
+    words = multi_gpu.pack_rows(rows, 6, 2, bases, TILE)
+    assert len(words) == 6 + 1 + 3 * 2 and int(words[6]) == 4 | (1 << 40)
+    assert np.array_equal(multi_gpu.unpack_rows(words, 6, 2, bases, TILE), rows)
+    with pytest.raises(ValueError):
+        multi_gpu.pack_rows(rows, 3, 2, bases, TILE)                    # more rows than the buffer holds
+    with pytest.raises(ValueError):
+        multi_gpu.pack_rows(rows, 6, 0, bases, TILE)                    # no room for the long row
+    big = rows.copy()
+    big["k"][0] = 512
+    with pytest.raises(ValueError):
+        multi_gpu.pack_rows(big, 6, 2, bases, TILE)                     # motif sizes above 511 do not fit the wire row
 
 
 def test_plan_parts_covers_the_genome_in_order_at_tile_multiples():
@@ -113,15 +160,12 @@ def _failing_worker(rank, world, port):
     import torch.distributed as dist
     import multi_gpu
     dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    def scan(seqs, settings):
-        if rank == 1:
-            raise ValueError("unsupported symbol at contig 0 position 4")
-        return _oracle_scan(seqs, settings)
     try:
+        error = ValueError("unsupported symbol at contig 0 position 4") if rank == 1 else None
         with pytest.raises(multi_gpu.ShardError) as info:           # on BOTH ranks, with rank 1's message, before any row collective
-            multi_gpu.scan_contigs_sharded(_contigs(), (1, 20, 3, 9), scan, dist, torch, "cpu")
+            multi_gpu.agree_or_raise(error, dist, torch, "cpu")
         assert info.value.rank == 1 and info.value.kind == "ValueError" and "position 4" in info.value.message
+        multi_gpu.agree_or_raise(None, dist, torch, "cpu")          # nobody failed: returns on every rank
     finally:
         dist.barrier()
         dist.destroy_process_group()

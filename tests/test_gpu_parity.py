@@ -35,6 +35,11 @@ def detect(ctx):
     return run
 
 
+def prf_native_flags():
+    import prf_native
+    return prf_native
+
+
 def rows_as_tuples(rows):
     return [(int(r["contig"]), int(r["start"]), int(r["end"]), int(r["k"])) for r in rows]
 
@@ -344,6 +349,9 @@ def test_errors_cross_the_boundary_cleanly(ctx):
     with pytest.raises(prf_native.PrfError) as info:
         ctx.scan_literal(b"ACGT-ACGT", 1, 5, 1, 1)
     assert info.value.code == prf_native.PRF_ESYMBOL and "position 4" in info.value.message
+    with pytest.raises(prf_native.PrfError) as info:         # the position names the contig's own coordinate, N trimmed or not
+        ctx.scan([b"NNNACGT-ACGT"], 1, 5, 1, 1)
+    assert info.value.code == prf_native.PRF_ESYMBOL and "position 7" in info.value.message
     with pytest.raises(prf_native.PrfError) as info:
         ctx.scan([b"ACGT"], 0, 5, 3, 9)
     assert info.value.code == prf_native.PRF_EINVAL
@@ -575,6 +583,55 @@ def test_config_c4_hg38_sized_genome_on_one_gpu(ctx):
         g.free()
 
 
+BENCH_DEFAULT_ROWS = 5_699_373
+BENCH_DEFAULT_ROWS_SHA256 = "0a363624c734e86942f2d8ccfc2822b2b4e3dcd4ced115f46fd503af8f865d7b"   # printed by bench.py as config.rows_sha256_rank0
+
+
+def test_bench_default_workload_at_full_size(ctx):
+    """The workload bench.py times by default: 25 contigs with the hg38 primary-assembly lengths, the stand-in
+    recipe generated on the device (seeds 1000...), motif 1-50.  The number in BENCH_r03 is tied to THIS row set: fused ==
+    generic row for row; the oracle on windows of the host recipe at both N-block edges and both gap edges of three contigs;
+    the eight shares of an 8-GPU run (multi_gpu.plan_parts) concatenate to the whole scan; the SHA-256 of the row array is the
+    one bench.py prints (config.rows_sha256_rank0)."""
+    import hashlib
+    import multi_gpu
+    import prf_native
+    import synth
+    from oracle import prf_oracle
+    seeds = [1000 + i for i in range(len(HG38_LENS[:25]))]
+    lens = HG38_LENS[:25]
+    g = ctx.standin(lens, seeds, 50)
+    try:
+        rows, st = g.scan(1, 50, 3, 9)
+        assert st.path == 1 and st.sorted_on_device == 1 and st.n_launches == 2 and len(rows) == BENCH_DEFAULT_ROWS
+        assert hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest() == BENCH_DEFAULT_ROWS_SHA256
+        gen, stg = g.scan(1, 50, 3, 9, flags=prf_native.SCAN_FORCE_GENERIC)
+        assert stg.path == 0 and np.array_equal(rows, gen)
+        contig, starts, ends, ks = (rows[f].astype(np.int64) for f in ("contig", "start", "end", "k"))
+        win, margin = 400_000, 1_000
+        for c in (0, 11, 22):
+            n = lens[c]
+            n_head, n_tail, gap_lo, gap_hi = synth.standin2_layout(n)
+            for off in (0, gap_lo - win // 2, gap_hi - win // 2, n - win):      # both N blocks' edges, both gap edges
+                chunk = synth.standin2(n, seeds[c], off, win).tobytes()
+                want = [(s + off, e + off, k) for s, e, _m, k in prf_oracle.detect_rows(chunk, 1, 50, 3, 9)
+                        if s >= margin and e <= win - margin]
+                sel = (contig == c) & (starts >= off + margin) & (ends <= off + win - margin)
+                got = list(zip(starts[sel].tolist(), ends[sel].tolist(), ks[sel].tolist()))
+                assert got == want and len(want) > 100, (c, off)
+        shares = multi_gpu.plan_parts(lens, 8, prf_native.tile_positions(), [g.tile_classes(c) for c in range(len(lens))])
+        pieces = []
+        for share in shares:
+            g.select(share)
+            r, s_ = g.scan(1, 50, 3, 9)
+            assert s_.sorted_on_device == 1
+            pieces.append(r)
+        g.select([])
+        assert min(len(p) for p in pieces) > 0.8 * len(rows) / 8 and np.array_equal(np.concatenate(pieces), rows)
+    finally:
+        g.free()
+
+
 def test_config_c3_chr1_sized_stand_in_generated_on_the_device(ctx):
     """BASELINE config C3's workload as bench.py --workload chr1 times it: a chr1-sized contig (248 956 422 bp) of the stand-in
     recipe (N blocks at both ends, a 10 Mbp centromere-like gap, one planted repeat per 588 positions), generated on the
@@ -678,6 +735,10 @@ def test_deferred_timings_and_device_hand_off_with_count_record(ctx):
         ctx.set_row_sink(buf.data_ptr(), 10)
         with pytest.raises(prf_native.PrfError):
             g.scan(1, 50, 3, 9)
+        ctx.set_row_sink(buf.data_ptr(), cap)                # the literal lane hands its rows over on the host: refused with a sink
+        with pytest.raises(prf_native.PrfError) as info:
+            ctx.scan([b"ACGTACGTACGT"], 1, 5, 1, 9)
+        assert info.value.code == prf_native.PRF_EUNSUPPORTED
         ctx.set_row_sink(None, 0)
         rows4, _ = g.scan(1, 50, 3, 9)
         assert np.array_equal(rows4, rows)
@@ -723,6 +784,9 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
         assert ctx.last_hits_packed_to_device(g, words.data_ptr(), cap, side) == len(rows)
         got = multi_gpu.unpack_rows(words.cpu().numpy(), cap, side, g.contig_bases(), prf_native.tile_positions())
         assert np.array_equal(got, rows)
+        # the host reference encoder (what the 2-rank gloo test of the product path sends) writes the same words
+        assert np.array_equal(multi_gpu.pack_rows(rows, cap, side, g.contig_bases(), prf_native.tile_positions()),
+                              words.cpu().numpy().view(np.uint64))
         with pytest.raises(prf_native.PrfError):
             ctx.last_hits_packed_to_device(g, words.data_ptr(), len(rows) - 1, side)       # too small: refused
     finally:
@@ -736,6 +800,27 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
         words = torch.zeros(len(rows) + 1 + 3 * 4, dtype=torch.int64, device="cuda")
         ctx.last_hits_packed_to_device(g, words.data_ptr(), len(rows), 4)
         assert np.array_equal(multi_gpu.unpack_rows(words.cpu().numpy(), len(rows), 4, g.contig_bases(), prf_native.tile_positions()), rows)
+        host_words = multi_gpu.pack_rows(rows, len(rows), 4, g.contig_bases(), prf_native.tile_positions())
+        dev_words = words.cpu().numpy().view(np.uint64)
+        n_side = int(dev_words[len(rows)]) >> 40                                           # (the device fills the side list in any order)
+        assert n_side == 2 and np.array_equal(host_words[:len(rows) + 1], dev_words[:len(rows) + 1])
+        assert sorted(map(tuple, host_words[len(rows) + 1:len(rows) + 1 + 3 * n_side].reshape(-1, 3).tolist())) == \
+            sorted(map(tuple, dev_words[len(rows) + 1:len(rows) + 1 + 3 * n_side].reshape(-1, 3).tolist()))
+    finally:
+        g.free()
+    # motif sizes above 511 do not fit the wire row: the hand-off is refused (it used to truncate k silently), the whole rows leave
+    import synth
+    wide = synth.synth_bases(600, 77).tobytes() * 3 + b"TTGACCA"
+    g = ctx.load([wide], 600)
+    try:
+        rows, st = g.scan(590, 600, 2, 9)
+        assert st.path == 0 and rows_as_tuples(rows) == [(0, a, b, k) for a, b, k in oracle_rows(wide, 590, 600, 2, 9)] and len(rows) >= 1
+        words = torch.zeros(len(rows) + 1 + 3 * 4, dtype=torch.int64, device="cuda")
+        with pytest.raises(prf_native.PrfError) as info:
+            ctx.last_hits_packed_to_device(g, words.data_ptr(), len(rows), 4)
+        assert info.value.code == prf_native.PRF_EUNSUPPORTED
+        buf = torch.zeros((len(rows) + 1, 3), dtype=torch.int64, device="cuda")
+        assert ctx.last_hits_to_device(buf.data_ptr(), len(rows)) == len(rows)
     finally:
         g.free()
     # dense tiles (round 3): 799 rows per tile -- more than the LDS row list holds (the densest tile of the reference's golden
@@ -751,6 +836,35 @@ def test_rows_leave_the_device_sorted_and_dense_tiles_fall_back(ctx):
     densest = (b"ACACACACACAC" + b"GTTGCAGA") * 9000
     rows, st = ctx.scan([densest], 1, 6, 3, 9)
     assert st.sorted_on_device == 0 and [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)] == oracle_rows(densest, 1, 6, 3, 9)
+
+
+def test_chr22_real_golden_bed_clusters_at_their_real_coordinates(ctx):
+    """The workload with the REAL genome's row clustering: every cluster of the reference's golden
+    benchmark/repeat_finder/chr22_repeats.bed planted at its real coordinate in the chr22 stand-in (synth.chr22_real; the
+    clusters were re-run through the reference itself by oracle/gen_golden.py).  At the BED's own settings (motif 1-6, r 3,
+    span 9) the whole scan equals the oracle's, holds every planted golden row, leaves the device sorted -- the densest tile has
+    759 rows, more than the LDS row list: ranked in the dead image region -- and takes ONE pass (no slab overflow, no second
+    scan).  At motif 1-50 fused == generic row for row."""
+    import synth
+    seq, planted = synth.chr22_real()
+    lo, hi = 10_510_000, len(seq) - 10_000
+    g = ctx.load([seq.tobytes()], 50)
+    try:
+        rows, st = g.scan(1, 6, 3, 9)
+        assert st.path == 1 and st.sorted_on_device == 1 and st.n_launches == 2       # one scan kernel + one gather: no retry
+        want = oracle_rows(seq[lo:hi].tobytes(), 1, 6, 3, 9)
+        got = [(s, e, k) for _c, s, e, k in rows_as_tuples(rows)]
+        assert got == [(s + lo, e + lo, k) for s, e, k in want] and len(got) == 76_570
+        have = set(got)
+        assert all((int(s), int(e), int(k)) in have for s, e, k in planted.tolist())
+        import collections
+        assert max(collections.Counter(s // 65_536 for s, _e, _k in got).values()) == 759
+        rows50, st50 = g.scan(1, 50, 3, 9)
+        assert st50.path == 1 and st50.sorted_on_device == 1 and st50.n_launches == 2
+        gen50, stg = g.scan(1, 50, 3, 9, flags=prf_native_flags().SCAN_FORCE_GENERIC)
+        assert stg.path == 0 and np.array_equal(rows50, gen50) and len(rows50) > len(rows)
+    finally:
+        g.free()
 
 
 def test_parts_of_one_genome_scanned_separately_add_up_to_the_whole_scan(ctx):
