@@ -50,10 +50,12 @@ HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
-def pmc_traffic(workload, kmin, kmax):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    None if no committed measurement matches this workload."""
+def pmc_record(workload, kmin, kmax):
+    """The committed rocprofv3 PMC measurement of this workload (profiles/pmc_traffic.json): HBM bytes per launch of the
+    scan kernel (and of the row gather) -- FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 -- and the share of the VALU issue cycles the scan kernel uses.  A constant
+    looked up in a committed file, not a live counter (rocprofv3 cannot run inside the timed process); None if no
+    committed measurement matches this workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
@@ -61,7 +63,7 @@ def pmc_traffic(workload, kmin, kmax):
         with open(path) as f:
             for rec in json.load(f):
                 if rec.get("workload") == workload and rec["kmin"] == kmin and rec["kmax"] == kmax:
-                    return rec["hbm_bytes_per_launch"]
+                    return rec
     except (ValueError, KeyError):
         pass
     return None
@@ -75,44 +77,85 @@ def _oracle_chunk(job):
     return n, time.perf_counter() - t0
 
 
+def _physical_cores(cpus):
+    """one hardware thread per physical core among `cpus` (thread_siblings_list of sysfs; all of them if that is unreadable)"""
+    seen, out = set(), []
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
+def _many_cores(sample, cpus, settings, rounds=3):
+    """Every cpu of `cpus` scans its own window of the sample at the same time, `rounds` times; the median wall time of a
+    round.  Reproducible: one worker process per cpu, pinned to it (os.sched_setaffinity), started ONCE;
+    the windows are cut before the fork; a round runs from a barrier every worker has reached to a barrier every worker has
+    reached again, so that starting the processes and their scheduling jitter are not part of the rate."""
+    import multiprocessing as mp
+    n = len(cpus)
+    win = max(1, len(sample) // 8)                                   # an eighth of the sample: ~0.7 s of work
+    starts = [(len(sample) - win) * i // max(1, n - 1) for i in range(n)]
+    jobs = [(sample[st:st + win],) + settings for st in starts]     # windows spread evenly over the sample, overlapping
+    mpc = mp.get_context("fork")
+    gate_in, gate_out = mpc.Barrier(n + 1), mpc.Barrier(n + 1)
+
+    def worker(i):
+        try:
+            os.sched_setaffinity(0, {cpus[i]})
+        except OSError:
+            pass
+        for _ in range(rounds):
+            gate_in.wait()
+            _oracle_chunk(jobs[i])
+            gate_out.wait()
+
+    procs = [mpc.Process(target=worker, args=(i,)) for i in range(n)]
+    for p in procs:
+        p.start()
+    walls = []
+    try:
+        for _ in range(rounds):
+            gate_in.wait(timeout=300)
+            t0 = time.perf_counter()
+            gate_out.wait(timeout=600)
+            walls.append(time.perf_counter() - t0)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+    if len(walls) != rounds or any(p.exitcode != 0 for p in procs):
+        return None
+    wall = sorted(walls)[rounds // 2]
+    return {"value": n * win / wall / 1e9, "unit": "Gbp/s", "cores": n,
+            "note": f"{n} pinned processes of the oracle, one {win} bp window of the sample each, median of {rounds} rounds "
+                    f"({', '.join(f'{w:.2f}' for w in walls)} s), a round = barrier to barrier"}
+
+
 def cpu_baseline(sample, kmin, kmax, min_repeats, min_span, what):
     """Oracle (kind 'port': C restatement of the reference's state machine) on a bounded sample: one thread on the
-    whole sample, then every host core on a window of it at the same time (the reference's own parallel strategy is
-    independent interval jobs, one CPU each: hail_batch_pipeline/run_hail_batch_pipeline.py:101)."""
-    import multiprocessing as mp
-    n_rows, dt = _oracle_chunk((sample, kmin, kmax, min_repeats, min_span))
-    cores = max(1, len(os.sched_getaffinity(0)))
+    whole sample, then many cores on windows of it at the same time -- one process per hardware thread, and one per physical
+    core (the reference's own parallel strategy is independent interval jobs, one CPU each:
+    hail_batch_pipeline/run_hail_batch_pipeline.py:101)."""
+    settings = (kmin, kmax, min_repeats, min_span)
+    n_rows, dt = _oracle_chunk((sample,) + settings)
+    cpus = sorted(os.sched_getaffinity(0))
     out = {"value": len(sample) / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
            "sample": f"{what}, motif {kmin}-{kmax}, {n_rows} rows, {dt:.1f} s single-thread C oracle (the pure-Python "
                      f"reference runs ~0.018 Mbp/s at motif 1-50, BASELINE.md)"}
-    if cores > 1:
-        # every core scans its own window of the sample (an eighth of it: ~0.7 s of work, windows spread evenly and
-        # overlapping); the clock runs from a barrier all workers have reached to the last one's finish, so that starting
-        # the processes is not part of the rate
-        win = max(1, len(sample) // 8)
-        starts = [(len(sample) - win) * i // max(1, cores - 1) for i in range(cores)]
-        mpc = mp.get_context("fork")
-        gate = mpc.Barrier(cores + 1)
-        ends = mpc.Array("d", cores)
-
-        def worker(i):
-            job = (sample[starts[i]:starts[i] + win], kmin, kmax, min_repeats, min_span)
-            gate.wait()
-            _oracle_chunk(job)
-            ends[i] = time.perf_counter()                     # (CLOCK_MONOTONIC: one clock for all processes)
-
-        procs = [mpc.Process(target=worker, args=(i,)) for i in range(cores)]
-        for p in procs:
-            p.start()
-        gate.wait()
-        t0 = time.perf_counter()
-        for p in procs:
-            p.join()
-        if all(p.exitcode == 0 for p in procs):
-            wall = max(ends[:]) - t0
-            out["all_cores"] = {"value": cores * win / wall / 1e9, "unit": "Gbp/s", "cores": cores,
-                                "note": f"{cores} processes of the oracle, one {win} bp window of the sample each, {wall:.1f} s from a "
-                                        f"common start to the last finish"}
+    if len(cpus) > 1:
+        res = _many_cores(sample, cpus, settings)
+        if res:
+            out["all_cores"] = res
+        phys = _physical_cores(cpus)
+        if 1 < len(phys) < len(cpus):
+            res = _many_cores(sample, phys, settings)
+            if res:
+                out["physical_cores"] = res
     return out
 
 
@@ -176,7 +219,7 @@ def main():
     ap.add_argument("--generic", action="store_true", help="force the generic kernel")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N=1: wait for every scan before the next is enqueued (default: two scans in flight)")
-    ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the rows to rank 0 every this many steps")
+    ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the rows to rank 0 every this many steps (0: never)")
     args = ap.parse_args()
     if not args.kmax:
         args.kmax = 100 if args.workload == "random" else 50
@@ -250,10 +293,11 @@ def main():
             free_q.put(b)
         comm_state = {"last": None, "error": None, "gather_s": [], "n": 0}
 
+        comm_stream = torch.cuda.Stream()      # the send buffers are handed to it on the device (prf_stream_wait_for): no host wait
+
         def comm_loop():
             try:
                 torch.cuda.set_device(dev_index)
-                comm_stream = torch.cuda.Stream()
                 with torch.cuda.stream(comm_stream):
                     while True:
                         item = work_q.get()
@@ -285,17 +329,29 @@ def main():
     step_no = [0]
 
     def step():
+        """one synchronous step (--no-pipeline, the generic kernel): the host waits for the scan and, at N > 1, for the pack"""
+        _, st = scan(False)
         if world > 1:
-            b = take_buffer()                                                # blocks only if all NBUF gathers are pending
-            _, st = scan(False)                                              # rows sorted and compact on the device ...
             step_no[0] += 1
-            do_gather = step_no[0] % args.gather_every == 0
-            if do_gather:                                                    # ... packed into the send buffer: 8 bytes a row
+            if args.gather_every > 0 and step_no[0] % args.gather_every == 0:
+                b = take_buffer()
                 ctx.last_hits_packed_to_device(genome, send_devs[b].data_ptr(), gather_cap, SIDE)
-            work_q.put((b, do_gather))
-        else:
-            _, st = scan(False)
+                work_q.put((b, True))
         return st
+
+    def enqueue_sharded():
+        """N > 1: one scan of this rank's share enqueued, its rows packed to 8-byte wire rows on the library's stream behind it
+        (no host step in between), the send buffer handed to the communication stream by an event: the host neither waits for
+        the scan nor for the pack.  Returns the scan's serial number (collected one step later, like at N = 1)."""
+        step_no[0] += 1
+        do_gather = args.gather_every > 0 and step_no[0] % args.gather_every == 0
+        if not do_gather:
+            return genome.scan_async(args.kmin, args.kmax, args.min_repeats, args.min_span)
+        b = take_buffer()                                                    # blocks only if all NBUF gathers are pending
+        seq = genome.scan_async_packed(args.kmin, args.kmax, args.min_repeats, args.min_span, send_devs[b].data_ptr(), gather_cap, SIDE)
+        ctx.stream_wait_for(comm_stream.cuda_stream)
+        work_q.put((b, True))
+        return seq
 
     def fence():
         if world > 1:
@@ -305,14 +361,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = world == 1 and st0.path == 1 and not args.generic and not args.no_pipeline
+    pipelined = st0.path == 1 and not args.generic and not args.no_pipeline and (world == 1 or args.kmax <= 511)
 
     def run_pipelined(n):
         """n steps with two scans in flight: scan i+1 is enqueued before scan i is collected, so its launch and the
         host's share overlap the kernels of scan i.  Every scan is collected (row count checked) inside the call."""
         out, pending = [], None
         for _ in range(n):
-            s = genome.scan_async(args.kmin, args.kmax, args.min_repeats, args.min_span)
+            s = enqueue_sharded() if world > 1 else genome.scan_async(args.kmin, args.kmax, args.min_repeats, args.min_span)
             if pending is not None:
                 out.append(ctx.scan_wait(pending))
             pending = s
@@ -352,6 +408,8 @@ def main():
     else:
         p1 = float(np.mean(p1_ms)) if p1_ms else 0.0
     kernel_ms_ranks = [p1]
+    both_ms = p1 + (float(np.mean(gather_kernel_ms)) if gather_kernel_ms is not None else 0.0)   # scan + row gather kernels of this rank
+    both_ms_max = both_ms
     if world > 1:
         t = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -362,6 +420,9 @@ def main():
         km = [torch.zeros(1, device=tdev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(km, torch.tensor([p1], device=tdev, dtype=torch.float64))
         kernel_ms_ranks = [float(x.item()) for x in km]
+        bm = torch.tensor([both_ms], device=tdev, dtype=torch.float64)
+        dist.all_reduce(bm, op=dist.ReduceOp.MAX)
+        both_ms_max = float(bm.item())
     else:
         n_rows_total = n_rows_local
 
@@ -379,8 +440,13 @@ def main():
         # algorithmic bytes per launch of the dominant kernel: the 2-bit input once for all k,
         # plus the 24-byte rows -- of this rank's share
         bytes_alg = (my_bp + 3) // 4 + 24 * n_rows_local
-        achieved = bytes_alg / (p1 * 1e-3) / 1e9 if p1 else 0.0
+        # t_scan of SURVEY 8(d): first scan-kernel start -> compacted rows ready = scan kernel + row gather (HIP events on the
+        # library's stream around every launch of the timed region); the scan kernel alone is the labelled secondary
+        t_scan = both_ms if st0.path == 1 else p1
+        achieved = bytes_alg / (t_scan * 1e-3) / 1e9 if t_scan else 0.0
+        achieved_scan_only = bytes_alg / (p1 * 1e-3) / 1e9 if p1 else 0.0
         hbm_meas = ctx.measure_hbm_read(1 << 30, 5)
+        pmc = pmc_record(args.workload, args.kmin, args.kmax) if (st0.path == 1 and world == 1) else None
         out = {
             "metric": f"Gbp/s scanned (motif {args.kmin}-{args.kmax})", "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -395,6 +461,8 @@ def main():
                        "rows_sha256_rank0": rows_sha256, "launches_of_the_untimed_scan": int(st0.n_launches),
                        "candidate_records_rank0": int(st0.n_candidates),
                        "steps_in_flight": 2 if pipelined else 1,
+                       # what the host adds to a step beyond the slowest rank's two kernels (launches, polling, hand-off to the gather)
+                       "host_overhead_ms_per_step": round(ms_per_step - both_ms_max, 5),
                        "multi_gpu": ({"sharding": "every rank holds the genome and scans its share of the tiles (prf_genome_select); "
                                                   "no data-path collective",
                                       "gather": f"one padded RCCL gather of 8-byte wire rows (prf_last_hits_packed_to_device) to rank 0 every "
@@ -405,14 +473,19 @@ def main():
                                       "scan_kernel_ms_per_rank": [round(x, 5) for x in kernel_ms_ranks]} if world > 1 else "n/a")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": pmc_traffic(args.workload, args.kmin, args.kmax) if (st0.path == 1 and world == 1) else None,
-                         "kernel": "prf_vscan_kernel (fused scan + verify + per-tile sorted rows)" if st0.path == 1 else "prf_scan_generic_kernel",
+                         "traffic": (pmc["hbm_bytes_per_launch"] + pmc.get("gather_hbm_bytes_per_launch", 0)) if pmc else None,
+                         "traffic_source": ("profiles/pmc_traffic.json: " + pmc.get("note", "")) if pmc else None,
+                         "valu_busy": pmc.get("valu_busy") if pmc else None,
+                         "kernel": ("prf_vscan_kernel (fused scan + verify + per-tile sorted rows) + prf_vgather_kernel (slabs -> one sorted "
+                                    "array): t_scan of SURVEY 8(d)") if st0.path == 1 else "prf_scan_generic_kernel",
+                         "t_scan_ms": round(t_scan, 5),
                          "kernel_ms": round(p1, 5),
                          "kernel_ms_min_median": [round(float(np.min(scan_ms)), 5), round(float(np.median(scan_ms)), 5)] if scan_ms is not None else None,
-                         "gather_kernel_ms": round(float(np.mean(gather_kernel_ms)), 5) if gather_kernel_ms else None,
+                         "gather_kernel_ms": round(float(np.mean(gather_kernel_ms)), 5) if gather_kernel_ms is not None else None,
+                         "scan_kernel_only": {"achieved": round(achieved_scan_only, 2), "frac": round(achieved_scan_only / HBM_PEAK_GBPS, 5)},
                          "algorithmic_bytes_per_launch": bytes_alg,
                          # the same counting only the tiles that are launched (tiles of nothing but N are skipped)
-                         "achieved_nonN": round(((int(st0.tiles_launched) * 65536) // 4 + 24 * n_rows_local) / (p1 * 1e-3) / 1e9, 2) if p1 else None,
+                         "achieved_nonN": round(((int(st0.tiles_launched) * 65536) // 4 + 24 * n_rows_local) / (t_scan * 1e-3) / 1e9, 2) if t_scan else None,
                          "measured_hbm_read_GBps": round(hbm_meas, 1),
                          "frac_of_measured_read": round(achieved / hbm_meas, 5)},
         }

@@ -68,6 +68,8 @@ struct prf_ctx {
     u64 *h_counters = nullptr;   // pinned, device-mapped: the fused path's last kernel writes the counters here
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
+    u64 *d_side_cnt = nullptr;   // pipelined wire hand-off: long rows packed so far (zero between packs)
+    hipEvent_t ev_handoff = nullptr;  // prf_stream_wait_for
     u32 parity = 0;
     u64 scan_seq = 0;
     // generic path scratch
@@ -189,6 +191,9 @@ int prf_open(int device_id, prf_ctx **out) {
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0));
     HIPCHK(hipMalloc((void **)&c->d_vcounters, 2 * PRF_CNT_N * sizeof(u64)));
     HIPCHK(hipMemset(c->d_vcounters, 0, 2 * PRF_CNT_N * sizeof(u64)));
+    HIPCHK(hipMalloc((void **)&c->d_side_cnt, sizeof(u64)));
+    HIPCHK(hipMemset(c->d_side_cnt, 0, sizeof(u64)));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_handoff, hipEventDisableTiming));
     guard.c = nullptr;
     *out = c;
     return PRF_OK;
@@ -203,6 +208,8 @@ void prf_close(prf_ctx *c) {
     (void)hipHostFree(c->h_async);
     (void)hipFree(c->d_hits_async);
     (void)hipFree(c->d_vcounters);
+    (void)hipFree(c->d_side_cnt);
+    if (c->ev_handoff) (void)hipEventDestroy(c->ev_handoff);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
     (void)hipFree(c->d_slabs);
@@ -1078,7 +1085,7 @@ int prf_scan(prf_ctx *c, const prf_contig *contigs, int n_contigs, uint32_t kmin
 // scan's kernel: kernels of one stream run back to back.  Fused path only, no row sink, buffers already sized by an
 // ordinary scan of the same genome and parameters; anything else is refused and the caller scans synchronously.
 static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,
-                           uint64_t *seq_out) {
+                           uint64_t *seq_out, const u64 **counters_out = nullptr, const prf_hit_dev **rows_out = nullptr) {
     if (!c || !g || !seq_out) return fail(PRF_EINVAL, "prf_scan_genome_async: bad arguments");
     if (g->ctx != c) return fail(PRF_EINVAL, "prf_scan_genome_async: genome belongs to another context");
     if (c->sink) return fail(PRF_EUNSUPPORTED, "prf_scan_genome_async: not with a row sink");
@@ -1117,6 +1124,8 @@ static int scan_async_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint3
     // the slabs before the next scan's tiles write them)
     u64 seq = 0;
     {
+        if (counters_out) *counters_out = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;  // (the block this scan counts in)
+        if (rows_out) *rows_out = sl.rows;
         const int rc = launch_fused(c, g, plan, min_repeats, min_span, sl.rows, c->hit_cap, 0u, sl.h_dev, &seq);
         if (rc) return rc;
     }
@@ -1136,6 +1145,36 @@ int prf_scan_genome_async(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32
     } catch (...) {
         return fail(PRF_EHIP, "prf_scan_genome_async: unexpected exception");
     }
+}
+
+// A pipelined scan whose rows leave as 8-byte wire words without the host in between: the pack kernels are enqueued behind the
+// scan's gather on the library's stream and read the row count from the scan's counter block (which the NEXT scan's gather
+// clears: stream order keeps it alive until then).
+int prf_scan_genome_async_packed(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span,
+                                 void *dst_device, uint64_t capacity_rows, uint64_t side_capacity, uint64_t *seq_out) {
+    try {
+        if (!dst_device) return fail(PRF_EINVAL, "prf_scan_genome_async_packed: no destination");
+        if (kmax > 511u) return fail(PRF_EUNSUPPORTED, "the 8-byte wire rows hold motif sizes up to 511 (max_motif_size %u)", kmax);
+        const u64 *counters = nullptr;
+        const prf_hit_dev *rows = nullptr;
+        const int rc = scan_async_impl(c, g, kmin, kmax, min_repeats, min_span, seq_out, &counters, &rows);
+        if (rc) return rc;
+        HIPCHK(prf_launch_pack_rows_dev(c->stream, rows, counters + PRF_CNT_ROWS, capacity_rows, g->d_base, (u64 *)dst_device, side_capacity,
+                                        c->d_side_cnt));
+        return PRF_OK;
+    } catch (...) {
+        return fail(PRF_EHIP, "prf_scan_genome_async_packed: unexpected exception");
+    }
+}
+
+// Everything enqueued on the library's stream so far happens before whatever is enqueued on `other_stream` (a hipStream_t)
+// from now on: the hand-off of a send buffer to a communication stream without a host wait.
+int prf_stream_wait_for(prf_ctx *c, void *other_stream) {
+    if (!c) return fail(PRF_EINVAL, "prf_stream_wait_for: NULL context");
+    HIPCHK(hipSetDevice(c->dev));
+    HIPCHK(hipEventRecord(c->ev_handoff, c->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)other_stream, c->ev_handoff, 0));
+    return PRF_OK;
 }
 
 int prf_scan_wait(prf_ctx *c, uint64_t seq, prf_scan_stats *stats) {
@@ -1299,29 +1338,9 @@ int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capac
 
 int prf_plan_describe(uint32_t kmin, uint32_t kmax, uint32_t min_repeats, uint32_t min_span, char *buf, uint64_t buf_len) {
     if (!buf || buf_len == 0) return fail(PRF_EINVAL, "prf_plan_describe: no buffer");
-    std::string out;
-    prf_vplan plan;
-    if (!prf_vertical_plan(kmin, kmax, min_repeats, min_span, &plan)) {
-        out = "{\"path\": \"generic\"}";
-    } else {
-        char tmp[160];
-        snprintf(tmp, sizeof tmp, "{\"path\": \"fused\", \"waves\": %u, \"nc\": %u, \"lds_bytes\": %u, \"tasks\": [", plan.n_waves,
-                 plan.nc, plan.lds_bytes);
-        out = tmp;
-        bool first = true;
-        for (u32 w = 0; w < plan.n_waves; w++)
-            for (u32 ti = plan.wave_begin[w]; ti < plan.wave_begin[w + 1]; ti++) {
-                const prf_vtask &t = plan.tasks[ti];
-                snprintf(tmp, sizeof tmp, "%s{\"wave\": %u, \"kind\": %u, \"k0\": %u, \"valid\": %u, \"stride\": %u}", first ? "" : ", ",
-                         w, (unsigned)t.kind, (unsigned)t.k0, (unsigned)t.valid, (unsigned)t.stride);
-                out += tmp;
-                first = false;
-            }
-        out += "]}";
-    }
-    if (out.size() + 1 > buf_len) return fail(PRF_EINVAL, "prf_plan_describe: buffer too small (%zu needed)", out.size() + 1);
-    memcpy(buf, out.c_str(), out.size() + 1);
-    return (int)out.size();
+    const int n = prf_plan_json(kmin, kmax, min_repeats, min_span, buf, buf_len);
+    if (n < 0) return fail(PRF_EINVAL, "prf_plan_describe: buffer too small");
+    return n;
 }
 
 void prf_free_hits(prf_hits *h) {

@@ -272,8 +272,15 @@ int prf_fasta_open_contig(const char *path, const char *name, prf_fasta **out) {
                             size_t stop = 0;  // a '>' inside the span: the index does not match the file
                             while (stop < got && buf[stop] != '>') stop++;
                             append_clean(seq, buf.data(), buf.data() + stop);
-                            if (seq.n > len) seq.n = len;
+                            // exactly `len` bases, and the record ends there: the next byte that is no line end is the '>' of
+                            // the next header or the end of the file.  An index whose length is too short would otherwise
+                            // hand over a truncated record without a word.
                             ok = seq.size() == len;
+                            if (ok && stop == got) {
+                                int ch;
+                                while ((ch = fgetc(f)) == '\n' || ch == '\r') {}
+                                ok = ch == EOF || ch == '>';
+                            }
                         }
                         fclose(f);
                         if (ok) {

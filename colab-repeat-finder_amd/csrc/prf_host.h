@@ -42,6 +42,10 @@ hipError_t prf_launch_hbm_read(hipStream_t s, const void *p, u64 bytes, u32 *sin
 hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, const u64 *contig_base, u64 *dst, u64 cap, u64 side_cap,
                                 u64 *side_cnt, u64 *host_word);
 
+// the same with the row count read on the device (behind a scan that is still in flight); side_cnt must be zero and is zero again afterwards
+hipError_t prf_launch_pack_rows_dev(hipStream_t s, const prf_hit_dev *rows, const u64 *n_ptr, u64 cap, const u64 *contig_base, u64 *dst,
+                                    u64 side_cap, u64 *side_cnt);
+
 // literal lane (scan_literal.hip): upper-case in place + first non-letter; one thread per (position, motif size) event
 hipError_t prf_launch_lit_upper(hipStream_t s, uint8_t *seq, u64 n, u64 *bad_pos);
 hipError_t prf_launch_lit_events(hipStream_t s, const uint8_t *seq, u64 L, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,

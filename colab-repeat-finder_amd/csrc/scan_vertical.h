@@ -6,12 +6,7 @@
 
 #include "prf_device.h"
 
-#define PRF_VMAX_K 480       // largest motif size the fused kernel takes (9-bit k field, LDS image width)
-#define PRF_VMAX_TASKS 80
-#define PRF_VMAX_WAVES 4
-#define PRF_GATHER_SLOTS_MAX 64u      // launch slots per workgroup of the row gather: 8 or 64 (gather_shift 3 / 6)
-#define PRF_GATHER_SUPER 64u          // gather workgroups per second-level sum
-#define PRF_LAUNCH_MIXED 0x80000000u  // launch-list entry: the tile has not-ACGT positions in reach
+#include "prf_plan.h"
 
 // Bit-sliced planes: see scan_vertical.hip for the layout.
 struct prf_vplanes {
@@ -24,38 +19,6 @@ struct prf_vplanes {
     u64 ntiles_alloc = 0;
     std::vector<unsigned char> h_class;   // host copies (planners, selections)
     std::vector<u32> h_list;
-};
-
-// One unit of scan work for one wave on one tile.
-//  kind 0     : "group" task -- the 8 motif sizes k0 .. k0+7 (k0 % 4 == 0) selected by `valid`, all with M(k) >= 15
-//  kind 1..14 : "exact" task -- the single motif size k0 (<= 14), whose minimum run length M(k0) equals `kind`
-struct prf_vtask {
-    unsigned short k0;
-    unsigned char kind;
-    unsigned char valid;
-    unsigned char stride;   // group tasks: examine every `stride`-th aligned group of 8 rows (1, 2 or 4)
-    unsigned char pad;
-    unsigned short item0;   // group tasks: index of the task's first motif size among all motif sizes of group tasks;
-                            // exact tasks: index among the exact tasks
-};
-
-// Work plan of one scan (host-built from kmin,kmax,min_repeats,min_span): tasks grouped per wave.
-struct prf_vplan {
-    u32 n_waves;                                // waves that have tasks (the workgroup always has PRF_VMAX_WAVES)
-    u32 n_tasks;
-    u32 wave_begin[PRF_VMAX_WAVES + 1];         // wave w runs tasks[wave_begin[w] .. wave_begin[w+1])
-    prf_vtask tasks[PRF_VMAX_TASKS];
-    u32 nc;                                     // virtual lanes of the LDS image (64 + extra)
-    u32 lds_bytes;
-    u32 cof_words;                              // entries of the cofactor table staged in LDS (covers 0 .. kmax)
-    u32 n_group_k;                              // motif sizes scanned by group tasks (boundary items of a tile)
-    u32 n_exact;                                // exact tasks: motif sizes k_exact0 .. k_exact0 + n_exact - 1 (item0 = k - k_exact0)
-    u32 k_exact0;
-    u32 ticket_wave;                            // the wave whose first lane draws the workgroup's next launch slot (it waits for the atomic)
-    u32 slack_waves;                            // bit w: wave w's scan work is < 90 % of the busiest wave's
-    u32 per_cu;                                 // workgroups per CU the plan's LDS and the kernel's registers allow
-    u32 prio;                                   // issue priorities (s_setprio), 2 bits each: stage | scan, busy wave << 2 | scan, slack
-                                                // wave << 4 | verify, flag waves << 6 | verify, record waves << 8 | rows << 10
 };
 
 // One row as the scan kernel leaves it in its tile's slab: 8 bytes.
@@ -109,8 +72,6 @@ struct prf_vgather_args {
     u64 *next_counters;            // ... and clears the block the next scan will use
 };
 
-// false if the parameters are outside what the fused kernel takes (-> generic kernel)
-bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vplan *plan);
 
 // ASCII (global coordinate space, G bytes) -> bit-sliced planes + tile classes + launch list. Synchronises the stream.
 int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp);

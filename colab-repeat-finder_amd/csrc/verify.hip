@@ -92,6 +92,44 @@ __global__ void prf_pack_finish_kernel(u64 *side_cnt, u64 n, u64 *count_word, u6
     *host_word = c;
 }
 
+// The same behind a scan that is still running (prf_scan_genome_async_packed): the row count is not known on the host, the
+// kernels read it from the scan's counter block; a count beyond the buffer's capacity becomes a poisoned count word.
+__global__ __launch_bounds__(256) void prf_pack_rows_dev_kernel(const prf_hit_dev *__restrict__ rows, const u64 *__restrict__ n_ptr,
+                                                                const u64 *__restrict__ contig_base, u64 *__restrict__ dst, u64 cap, u64 side_cap,
+                                                                u64 *__restrict__ side_cnt) {
+    const u64 n = *n_ptr;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n && i < cap; i += stride) {
+        const prf_hit_dev h = rows[i];
+        const u64 gpos = contig_base[h.contig] + h.start, span = h.end - h.start;
+        const u64 s16 = span < 65535ull ? span : 65535ull;
+        dst[i] = ((gpos >> 16) << 41) | ((gpos & 0xFFFFull) << 25) | (s16 << 9) | (u64)(h.k & 511u);
+        if (span >= 65535ull) {
+            const u64 j = atomicAdd(side_cnt, 1ull);
+            if (j < side_cap) {
+                u64 *o = dst + cap + 1 + 3 * j;
+                o[0] = h.start;
+                o[1] = h.end;
+                o[2] = (u64)h.k | ((u64)h.contig << 32);
+            }
+        }
+    }
+}
+__global__ void prf_pack_finish_dev_kernel(u64 *side_cnt, const u64 *n_ptr, u64 cap, u64 side_cap, u64 *count_word) {
+    const u64 c = *side_cnt, n = *n_ptr;
+    *count_word = (n > cap || c > side_cap) ? ~0ull : (n | (c << 40));   // all ones: the buffer was too small (multi_gpu.unpack_rows raises)
+    *side_cnt = 0;
+}
+
+hipError_t prf_launch_pack_rows_dev(hipStream_t s, const prf_hit_dev *rows, const u64 *n_ptr, u64 cap, const u64 *contig_base, u64 *dst,
+                                    u64 side_cap, u64 *side_cnt) {
+    const u64 blocks = (cap + 255) / 256;
+    hipLaunchKernelGGL(prf_pack_rows_dev_kernel, dim3((u32)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, s, rows, n_ptr, contig_base,
+                       dst, cap, side_cap, side_cnt);
+    hipLaunchKernelGGL(prf_pack_finish_dev_kernel, dim3(1), dim3(1), 0, s, side_cnt, n_ptr, cap, side_cap, dst + cap);
+    return hipGetLastError();
+}
+
 hipError_t prf_launch_pack_rows(hipStream_t s, const prf_hit_dev *rows, u64 n, const u64 *contig_base, u64 *dst, u64 cap, u64 side_cap,
                                 u64 *side_cnt, u64 *host_word) {
     if (n) hipLaunchKernelGGL(prf_pack_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, rows, n, contig_base, dst, cap, side_cap, side_cnt);

@@ -80,6 +80,8 @@ def unpack_rows(words, capacity, side_capacity, bases, tile):
     count word, 3 * side_capacity words of long rows.  bases: Genome.contig_bases().  Returns a ROW_DTYPE array."""
     words = np.asarray(words).view(np.uint64).reshape(-1)
     count = int(words[capacity])
+    if count == 0xFFFFFFFFFFFFFFFF:
+        raise ValueError("the packed row buffer was too small for the scan's rows (poisoned count word)")
     n, n_side = count & ((1 << 40) - 1), count >> 40
     w = words[:n]
     gpos = (w >> np.uint64(41)) * np.uint64(tile) + ((w >> np.uint64(25)) & np.uint64(0xFFFF))

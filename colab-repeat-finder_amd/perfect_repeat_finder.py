@@ -13,6 +13,7 @@ kernels.  The rows are bit-identical.  There is no CPU fallback:
 and a gfx950 device every scan raises.
 """
 import argparse
+import ctypes
 import os
 import re
 import sys
@@ -204,6 +205,39 @@ def _gpu_scan_whole_contigs(entries, settings, parts):
     return rows
 
 
+def _tile_classes_from_the_index(path, index, whole, dist, rank, world):
+    """Per-contig cost classes of the 65536-position tiles for multi_gpu.plan_parts (0 ordinary, 2 nothing but N: never
+    scanned).  The shares are then balanced by what is scanned, not by length (hg38's centromeres and telomeres are tens of
+    Mbp of N).  Contig c is looked at by rank c mod N only (through the index, or in the parsed file), the class arrays -- one
+    byte per 65536 positions -- are exchanged with one all_gather_object: every rank plans from the same classes, and no
+    rank reads the whole file for it."""
+    import numpy as np
+    tile = prf_native.tile_positions()
+    classes = []
+    for c, (name, n) in enumerate(index):
+        nt = -(-n // tile)
+        cls = np.zeros(nt, dtype=np.uint8)
+        if nt and c % world == rank:
+            if whole is not None:
+                e = whole[c]
+            else:
+                r = prf_native.Fasta(path, only=name)
+                e = r[0] if len(r) else None
+            if e is not None and e.length == n:
+                a = np.frombuffer((ctypes.c_char * n).from_address(e.addr), dtype=np.uint8)
+                is_n = (a | 0x20) == ord("n")
+                pad = np.ones(nt * tile - n, dtype=bool)
+                cls[np.concatenate((is_n, pad)).reshape(nt, tile).all(axis=1)] = 2
+        classes.append(cls)
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, [cls.tobytes() for cls in classes[rank::world]])
+        for r in range(world):
+            for i, raw in enumerate(everyone[r]):
+                classes[r + i * world] = np.frombuffer(raw, dtype=np.uint8)
+    return classes
+
+
 def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
     """The same under `python -m torch.distributed.run --nproc-per-node N perfect_repeat_finder.py genome.fa`: one
     process per GPU.  The genome is cut into N shares of equal size at tile multiples (multi_gpu.plan_parts: a contig longer
@@ -234,7 +268,8 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
             # the literal lane works on whole sequences (its rows depend on where a sequence begins and ends): whole contigs
             shares = multi_gpu.plan_whole_contigs(lens, world)
         else:
-            shares = multi_gpu.plan_parts(lens, world, prf_native.tile_positions())
+            shares = multi_gpu.plan_parts(lens, world, prf_native.tile_positions(),
+                                          _tile_classes_from_the_index(path, index, whole, dist, rank, world))
         mine = shares[rank]
         needed = sorted({c for c, _b, _e in mine})
         counts = np.zeros(len(index), dtype=np.int64)
@@ -244,7 +279,13 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
                 entries = [whole[c] for c in needed]
             else:
                 readers = [prf_native.Fasta(path, only=index[c][0]) for c in needed]    # one record each, by seeking
-                entries = [r[0] for r in readers]
+                entries = [r[0] if len(r) else None for r in readers]
+            # the shares were planned from the index: what was read must be what the index says, or the ranks would cut the
+            # genome differently from what they scan (a stale .fai) -- an error on every rank, never a short BED
+            for c, e in zip(needed, entries):
+                if e is None or e.length != index[c][1]:
+                    raise ValueError(f"{path}: contig {index[c][0]} has {'no record' if e is None else f'{e.length} bases'} in the file, "
+                                     f"its index says {index[c][1]}: rebuild {path}.fai (samtools faidx) or remove it")
             local = {c: i for i, c in enumerate(needed)}
             settings = (fs.min_motif_size, fs.max_motif_size, fs.min_repeats, fs.min_span)
             scan = scan_fn or (_gpu_scan_whole_contigs if fs.min_repeats < 2 else _gpu_scan_parts)
@@ -264,15 +305,22 @@ def _scan_whole_fasta_sharded(path, bed_path, fs, report, scan_fn=None):
         total = torch.from_numpy(counts).to(device)
         dist.all_reduce(total)
         dist.barrier()                                        # every part file is complete
+        # (one node, one working directory: the part files are read by rank 0 where the other ranks wrote them)
+        error = None
         if rank == 0:
-            with open(bed_path, "wb") as out:
-                for r in range(world):
-                    with open(f"{bed_path}.part{r}", "rb") as f:
-                        while True:
-                            chunk = f.read(1 << 24)
-                            if not chunk:
-                                break
-                            out.write(chunk)
+            try:
+                with open(bed_path, "wb") as out:
+                    for r in range(world):
+                        with open(f"{bed_path}.part{r}", "rb") as f:
+                            while True:
+                                chunk = f.read(1 << 24)
+                                if not chunk:
+                                    break
+                                out.write(chunk)
+            except Exception as exc:      # noqa: BLE001 -- disk full, a part file that is not there: the peers must not wait for ever
+                error = exc
+        multi_gpu.agree_or_raise(error, dist, torch, device)
+        if rank == 0:
             class _E:                                         # what report() reads: name and length
                 def __init__(self, name, n):
                     self.name, self._n = name, n

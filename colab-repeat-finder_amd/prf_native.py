@@ -65,10 +65,34 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
            "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split", "prf_last_hits_packed_to_device",
-           "prf_genome_contig_bases", "prf_scan_literal"]
+           "prf_genome_contig_bases", "prf_scan_literal", "prf_scan_genome_async_packed", "prf_stream_wait_for"]
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+class _HostOnly:
+    """A library that exports only the host-side entry points (FASTA reader, BED/TSV writers, planner): the prototypes of the
+    others are accepted and dropped, calling one raises.  Test infrastructure (tests/test_asan_host.py), selected by
+    PRF_LIB_HOST_ONLY=1 together with PRF_LIB."""
+
+    class _Absent:
+        def __init__(self, name):
+            self._name = name
+
+        def __call__(self, *args):
+            raise ImportError(f"{self._name} is not part of the host-only build")
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        try:
+            f = getattr(self._cdll, name)
+        except AttributeError:
+            f = _HostOnly._Absent(name)
+        self.__dict__[name] = f
+        return f
 
 
 def load_library():
@@ -81,6 +105,8 @@ def load_library():
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C colab-repeat-finder_amd/csrc).  There is no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)
+        if os.environ.get("PRF_LIB_HOST_ONLY") == "1":
+            lib = _HostOnly(lib)      # the sanitizer build of the host-only parts (make asan): the GPU entry points are absent
         vp = ctypes.c_void_p
         lib.prf_abi_version.restype = ctypes.c_int
         lib.prf_device_count.restype = ctypes.c_int
@@ -114,6 +140,9 @@ def load_library():
         lib.prf_last_hits_packed_to_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_genome_contig_bases.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_genome_async.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_scan_genome_async_packed.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [vp, ctypes.c_uint64, ctypes.c_uint64,
+                                                                                         ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_stream_wait_for.argtypes = [vp, vp]
         lib.prf_scan_wait.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(ScanStats)]
         lib.prf_scan_timings.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
         lib.prf_scan_timings_split.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float),
@@ -230,6 +259,15 @@ class Genome:
                                                                  ctypes.byref(seq)))
         return seq.value
 
+    def scan_async_packed(self, kmin, kmax, min_repeats, min_span, dst_ptr, capacity_rows, side_capacity):
+        """scan_async() whose rows also leave as 8-byte wire words in caller-owned device memory (capacity_rows + 1 +
+        3 * side_capacity words), packed on the library's stream behind the scan: no host step in between."""
+        seq = ctypes.c_uint64(0)
+        _check(self.ctx.lib, self.ctx.lib.prf_scan_genome_async_packed(self.ctx._h, self._h, kmin, kmax, min_repeats, min_span,
+                                                                        ctypes.c_void_p(dst_ptr), capacity_rows, side_capacity,
+                                                                        ctypes.byref(seq)))
+        return seq.value
+
     def free(self):
         if self._h is not None:
             self.ctx.lib.prf_genome_free(self._h)
@@ -314,6 +352,11 @@ class Context:
         _check(self.lib, self.lib.prf_last_hits_packed_to_device(self._h, genome._h, ctypes.c_void_p(dst_ptr), capacity_rows,
                                                                  side_capacity, ctypes.byref(n)))
         return n.value
+
+    def stream_wait_for(self, other_stream):
+        """What has been enqueued on the library's stream happens before what `other_stream` (a raw hipStream_t, e.g.
+        torch.cuda.Stream().cuda_stream) runs from now on."""
+        _check(self.lib, self.lib.prf_stream_wait_for(self._h, ctypes.c_void_p(other_stream)))
 
     def scan_wait(self, seq):
         """Collect a scan enqueued with Genome.scan_async(); returns its ScanStats (row and candidate counts)."""

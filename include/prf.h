@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PRF_ABI_VERSION 3
+#define PRF_ABI_VERSION 4
 
 typedef enum prf_status {
     PRF_OK = 0,
@@ -212,6 +212,17 @@ int prf_last_hits_to_device(prf_ctx *ctx, void *dst_device, uint64_t capacity_ro
  * PRF_EUNSUPPORTED if the last scan's max motif size exceeds 511 (k has 9 bits on the wire: hand such rows over whole). */
 int prf_last_hits_packed_to_device(prf_ctx *ctx, const prf_genome *g, void *dst_device, uint64_t capacity_rows,
                                    uint64_t side_capacity, uint64_t *n_rows);
+/* A pipelined scan (prf_scan_genome_async) whose rows leave in that wire format with no host step in between: the pack
+ * kernels run behind the scan on the library's stream and take the row count from the device.  dst_device as above; a scan
+ * with more rows than capacity_rows (or more long rows than side_capacity) leaves an all-ones count word, which
+ * multi_gpu.unpack_rows() refuses.  Collect the scan with prf_scan_wait() as usual. */
+int prf_scan_genome_async_packed(prf_ctx *ctx, const prf_genome *g, uint32_t kmin, uint32_t kmax, uint32_t min_repeats,
+                                 uint32_t min_span, void *dst_device, uint64_t capacity_rows, uint64_t side_capacity,
+                                 uint64_t *seq_out);
+/* Order: everything enqueued on the context's stream so far happens before what is enqueued on other_stream (a hipStream_t,
+ * e.g. torch.cuda.Stream().cuda_stream) from now on.  The hand-off of a send buffer to a communication stream. */
+int prf_stream_wait_for(prf_ctx *ctx, void *other_stream);
+
 /* First position of every contig in the genome's coordinate space (multiples of prf_tile_positions()). */
 int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capacity, uint64_t *n_contigs);
 

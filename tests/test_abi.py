@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"libprf.so does not export {name}"
     lib.prf_abi_version.restype = ctypes.c_int
-    assert lib.prf_abi_version() == 3
+    assert lib.prf_abi_version() == 4
 
 
 def test_binding_lists_the_same_symbols():

@@ -243,3 +243,33 @@ def test_command_line_under_two_ranks_writes_the_whole_genome_bed(tmp_path, capf
     mp.spawn(_cli_worker, args=(2, _free_port(), str(tmp_path), str(fasta), "one", ("--min-repeats", "1", "--min-span", "12")),
              nprocs=2, join=True)
     assert open(tmp_path / "one.bed").read() == want1
+
+
+def _stale_cli_worker(rank, world, port, workdir, fasta_path):
+    import pytest as _pytest
+    with _pytest.raises(Exception) as info:
+        _cli_worker(rank, world, port, workdir, fasta_path, "stale")
+    assert "index says" in str(info.value) and "ctg3" in str(info.value)            # on BOTH ranks, whoever read the contig
+
+
+def test_a_stale_index_is_an_error_on_every_rank_not_a_short_bed(tmp_path):
+    """the shares of the N-rank command line are planned from the .fai; an index whose lengths do not match the
+    file must not produce a BED that silently differs from the single-process one."""
+    import torch.multiprocessing as mp
+    contigs = {f"ctg{i}": c.decode() for i, c in enumerate(_contigs())}
+    fasta = tmp_path / "toy.fa"
+    off = 0
+    lines = []
+    with open(fasta, "wt") as f:
+        for name, seq in contigs.items():
+            f.write(f">{name}\n")
+            off += len(name) + 2
+            lines.append([name, len(seq), off, 70, 71])
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70] + "\n")
+            off += len(seq) + -(-len(seq) // 70)
+    lines[3][1] -= 1_000                                                                 # ctg3 (25 000 bp): the index says 24 000
+    with open(str(fasta) + ".fai", "wt") as f:
+        f.writelines("\t".join(map(str, ln)) + "\n" for ln in lines)
+    mp.spawn(_stale_cli_worker, args=(2, _free_port(), str(tmp_path), str(fasta)), nprocs=2, join=True)
+    assert not os.path.exists(tmp_path / "stale.bed") and not [p for p in os.listdir(tmp_path) if ".part" in p]

@@ -137,3 +137,55 @@ def test_single_record_access_with_and_without_an_index(tmp_path):
     with gzip.open(gz, "wb") as f:
         f.write(open(path, "rb").read())
     assert fetch(gz, "chr3") == [("chr3", names["chr3"])]
+    # an index whose LENGTH is stale (shorter than the record, same line geometry): the seek path must not hand over a
+    # truncated record -- it notices that the record goes on and parses the file instead
+    with open(str(path) + ".fai", "wt") as f:
+        f.writelines("\t".join([ln.split("\t")[0], str(int(ln.split("\t")[1]) - 7)] + ln.split("\t")[2:]) if ln.startswith("chr3") else ln
+                     for ln in fai)
+    assert fetch(path, "chr3") == [("chr3", names["chr3"])]
+    assert dict(prf_native.fasta_index(str(path))[0])["chr3"] == len(names["chr3"]) - 7      # (the index itself is what it is)
+
+
+def test_malformed_inputs_never_crash_the_reader(tmp_path):
+    """Untrusted files: random bytes, a header only, control characters, a truncated gzip stream, a directory, an index of
+    garbage -- every call returns (an error, or whatever records the bytes spell), none reads outside its buffers.  Run
+    under AddressSanitizer / UBSan by tests/test_asan_host.py."""
+    rng = np.random.default_rng(11)
+    blobs = [b"", b">", b">\n", b">a", b"\n\n\n", b"ACGT", b">a\n>b\n>c", b">x\r\nAC\rGT\r\n\r\n", b"\x00" * 100, b">n\n" + b"\xff" * 50,
+             b">" + b"A" * 10000 + b"\n" + b"C" * 3, b">a\n" + b"ACGT\n" * 1000 + b">a\n" + b"T" * 7]
+    blobs += [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in (1, 17, 4096, 70000)]
+    blobs += [b">r%d\n" % i + rng.choice(list(b"ACGTNacgtn\n>\r \t"), size=300).astype(np.uint8).tobytes() for i in range(20)]
+    for i, blob in enumerate(blobs):
+        path = str(tmp_path / f"m{i}.fa")
+        open(path, "wb").write(blob)
+        for only in (None, "a", "r3"):
+            try:
+                fa = prf_native.Fasta(path, only=only)
+                for e in fa:
+                    assert len(e.seq) == e.length
+                fa.close()
+            except prf_native.PrfError as exc:
+                assert exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ENOMEM)
+        # the same bytes behind an index of garbage
+        open(path + ".fai", "wb").write(rng.integers(0, 256, size=64, dtype=np.uint8).tobytes() + b"\na\t5\t3\t5\t6\nr3\t300\t4\t300\t301\n")
+        for only in ("a", "r3"):
+            try:
+                prf_native.Fasta(path, only=only).close()
+            except prf_native.PrfError:
+                pass
+        try:
+            prf_native.fasta_index(path)
+        except (prf_native.PrfError, ValueError):
+            pass
+    whole = gzip.compress(b">g\n" + b"ACGT" * 5000 + b"\n")
+    for cut in (0, 1, 10, len(whole) // 2, len(whole) - 1):
+        path = str(tmp_path / f"cut{cut}.fa.gz")
+        open(path, "wb").write(whole[:cut])
+        try:
+            prf_native.Fasta(path).close()
+        except prf_native.PrfError as exc:
+            assert exc.code == prf_native.PRF_EINVAL
+    try:
+        prf_native.Fasta(str(tmp_path))
+    except prf_native.PrfError as exc:
+        assert exc.code == prf_native.PRF_EINVAL
