@@ -77,6 +77,30 @@ def _oracle_chunk(job):
     return n, time.perf_counter() - t0
 
 
+def _usable_cpus():
+    """The cpus this process may run on, cut to the cgroup's CPU quota if there is one (a one-GPU share of a box shows all 256
+    hardware threads in its affinity mask but is granted 16 cpus' worth of time: 256 workers would time-share them)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, -(-int(quota) // int(period)))
+            phys = _physical_cores(cpus)
+            cpus = (phys if len(phys) >= n else cpus)[:n]
+    except (OSError, ValueError):
+        pass
+    return cpus
+
+
+def _quota_text():
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            return f.read().strip()
+    except OSError:
+        return "n/a"
+
+
 def _physical_cores(cpus):
     """one hardware thread per physical core among `cpus` (thread_siblings_list of sysfs; all of them if that is unreadable)"""
     seen, out = set(), []
@@ -143,7 +167,7 @@ def cpu_baseline(sample, kmin, kmax, min_repeats, min_span, what):
     hail_batch_pipeline/run_hail_batch_pipeline.py:101)."""
     settings = (kmin, kmax, min_repeats, min_span)
     n_rows, dt = _oracle_chunk((sample,) + settings)
-    cpus = sorted(os.sched_getaffinity(0))
+    cpus = _usable_cpus()
     out = {"value": len(sample) / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
            "sample": f"{what}, motif {kmin}-{kmax}, {n_rows} rows, {dt:.1f} s single-thread C oracle (the pure-Python "
                      f"reference runs ~0.018 Mbp/s at motif 1-50, BASELINE.md)"}
@@ -151,6 +175,7 @@ def cpu_baseline(sample, kmin, kmax, min_repeats, min_span, what):
         res = _many_cores(sample, cpus, settings)
         if res:
             out["all_cores"] = res
+            res["note"] += f" (affinity mask {len(os.sched_getaffinity(0))} cpus, cgroup quota {_quota_text()})"
         phys = _physical_cores(cpus)
         if 1 < len(phys) < len(cpus):
             res = _many_cores(sample, phys, settings)

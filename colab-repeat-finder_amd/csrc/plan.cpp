@@ -34,33 +34,44 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.stride = 1;
             // measured (stamps build, 6 workgroups per CU, units of 10 cycles): 4.9 k cycles for M <= 6 (one operation per
             // window), 5.4 k for M = 7 .. 9 (two), 6.0 k from M = 10 on (more rows of the next lane)
-            it.cost = M <= 6 ? 490u : (M <= 9 ? 545u : 600u);
+            // (from M = 7 on the task works on groups of rows, coarse_stream: 130 - 155 operations instead of 200 - 250)
+            it.cost = M <= 6 ? 490u : (M <= 8 ? 360u : (M <= 10 ? 400u : 350u));
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
+            // A group task takes the motif sizes k0 .. k0+7 (k0 a multiple of 4: whole 16-byte slots), or only the first four of
+            // them where the two halves want different strides (default thresholds: 8-11 every group, 12-19 every 2nd, 20..
+            // every 4th).  Examine every group, every 2nd or every 4th: a run of >= 8*S + 7 positions contains an aligned group
+            // of 8 whose index is a multiple of S.
             const u32 k0 = k & ~3u;
             u32 valid = 0;
+            long long mmin[2] = {1ll << 40, 1ll << 40};
             for (u32 kk = 0; kk < 8; kk++) {
                 const u32 kx = k0 + kk;
-                if (kx >= kmin && kx <= kmax && prf_plan_min_matches(kx, min_repeats, min_span) >= SMALL_M) valid |= 1u << kk;
+                const long long Mx = prf_plan_min_matches(kx, min_repeats, min_span);
+                if (kx >= kmin && kx <= kmax && Mx >= SMALL_M) {
+                    valid |= 1u << kk;
+                    mmin[kk >> 2] = std::min(mmin[kk >> 2], Mx);
+                }
             }
-            // examine every group, every 2nd or every 4th: a run of >= 8*S + 7 positions contains an aligned group
-            // of 8 whose index is a multiple of S
-            long long mmin = 1ll << 40;
-            for (u32 kk = 0; kk < 8; kk++)
-                if ((valid >> kk) & 1u) mmin = std::min(mmin, prf_plan_min_matches(k0 + kk, min_repeats, min_span));
-            const u32 stride = mmin >= 39 ? 4u : (mmin >= 23 ? 2u : 1u);
+            auto stride_of = [](long long m) { return m >= 39 ? 4u : (m >= 23 ? 2u : 1u); };
+            const bool both = (valid & 0x0Fu) && (valid & 0xF0u);
+            if (both && stride_of(mmin[0]) != stride_of(mmin[1])) valid &= 0x0Fu;  // the second half starts a task of its own
+            const bool half = (valid & 0xF0u) == 0;
+            const u32 stride = stride_of(half ? mmin[0] : std::min(mmin[0], mmin[1]));
             Item it;
             it.t.k0 = (unsigned short)k0;
             it.t.kind = 0;
             it.t.valid = (unsigned char)valid;
             it.t.stride = (unsigned char)stride;
-            // measured: 10.5 k / 5.1 k / 4.2 k cycles with 8 sizes, 2.2 k for stride 4 with 3
-            it.cost = stride == 1 ? 250u + 100u * (u32)__builtin_popcount(valid)
-                                  : (stride == 2 ? 110u + 50u * (u32)__builtin_popcount(valid) : 100u + 40u * (u32)__builtin_popcount(valid));
+            // measured (units of 10 cycles): 10.5 k / 5.1 k / 4.2 k cycles with 8 sizes, 2.2 k for stride 4 with 3; a task of four
+            // sizes reads three quarters of the rows of one of eight
+            const u32 n_sizes = (u32)__builtin_popcount(valid);
+            it.cost = stride == 1 ? 250u + 100u * n_sizes : (stride == 2 ? 110u + 50u * n_sizes : 100u + 40u * n_sizes);
+            if (half) it.cost += stride == 1 ? 130u : (stride == 2 ? 60u : 40u);
             items.push_back(it);
-            reach = std::max<u32>(reach, 24 + k0 + 15);
-            covered_to = k0 + 8;
+            reach = std::max<u32>(reach, 24 + k0 + (half ? 11 : 15));
+            covered_to = k0 + (half ? 4 : 8);
         }
     }
     if (items.size() > PRF_VMAX_TASKS) return false;

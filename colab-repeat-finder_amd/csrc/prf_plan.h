@@ -55,8 +55,8 @@ constexpr int LIN_POST = 24;                                  // ... and after i
 constexpr int TILE_WORDS = 1024;                              // 64-bit linear words per tile (PRF_TILE_WORDS)
 constexpr int LW = TILE_WORDS + LIN_PRE + LIN_POST;           // words per plane in the LDS window
 constexpr int REC_CAP = 192;                                  // group-task candidate records of a tile (one LDS list)
-constexpr int FLAG_CAP = 1024;                                // (stream, exact task) flags of a tile (one LDS list, 2 bytes each)
-constexpr int SLOW_CAP = 32;                                  // candidates of a tile that leave the LDS window: finished after the others
+constexpr int FLAG_CAP = 960;                                 // (stream, exact task) flags of a tile (one LDS list, 2 bytes each)
+constexpr int SLOW_CAP = 16;                                  // candidates of a tile that leave the LDS window: finished after the others
 constexpr int SMALL_M = 15;                                   // M(k) below this -> exact task
 constexpr int ROW_CAP_LDS = 448;                              // rows of a tile in the LDS list (more: the slab holds the rest, sorted in R1)
 constexpr int SMEM_HDR = 240;                                 // tile context, counters, next-slot words, long ends

@@ -676,19 +676,29 @@ struct Emit {
     prf_lds_u32 *cnt;        // this tile's counter set
     int lane;
 
-    // Exact tasks: the lanes' words of ONE task -> flags (lane | stream bit << 6 | task << 11) appended to the tile's list,
-    // ballot-compacted, one LDS atomic per round (a round takes one flag of every lane that has any left).  Flags beyond the
-    // list's capacity (a tile of long runs) are verified on the spot with the general routine.
+    // Exact tasks: the lanes' words of ONE task -> flags (lane | stream bit << 6 | task << 11) appended to the tile's list.
+    // ONE reservation per task (the stamps of the first version showed 2.7 k cycles per task in here against 2 k in the task
+    // itself: an LDS atomic round trip per round of the loop): a first pass of ballots counts the flags level by level (level j =
+    // the lanes with more than j flags), one atomic reserves them, a second pass places them -- level j behind the levels below
+    // it, a lane's flag behind those of the lower lanes.  Flags beyond the list's capacity (a tile of long runs) are verified on
+    // the spot with the general routine.
     __device__ __forceinline__ void push_flags(u32 word, u32 e, u32 k, prf_lds_u32 *flag_words) {
         typedef __attribute__((address_space(3))) unsigned short prf_lds_u16;
         prf_lds_u16 *list = (prf_lds_u16 *)flag_words;
+        const u32 pc = (u32)__builtin_popcount(word);
+        u32 total = 0;  // wave-uniform
+        for (u32 j = 0;; j++) {
+            const u64 bal = __builtin_amdgcn_ballot_w64(pc > j);
+            if (bal == 0) break;
+            total += (u32)__builtin_popcountll(bal);
+        }
+        if (total == 0) return;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd((u32 *)(cnt + CNT_FLAGS), total);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
         for (;;) {
             const u64 bal = __builtin_amdgcn_ballot_w64(word != 0);
             if (bal == 0) break;
-            const int first = (int)__builtin_ctzll(bal);
-            u32 base = 0;
-            if (lane == first) base = atomicAdd((u32 *)(cnt + CNT_FLAGS), (u32)__builtin_popcountll(bal));
-            base = (u32)__builtin_amdgcn_readlane((int)base, first);
             if (word) {
                 const u32 bit = (u32)__builtin_ctz(word);
                 word &= word - 1;
@@ -700,6 +710,7 @@ struct Emit {
                     verify_stream(reinterpret_cast<const TileCtx *>(prf_smem)->tile_base + (u64)(bit * 64u + (u32)lane) * T, k, 0u);
                 }
             }
+            base += (u32)__builtin_popcountll(bal);
         }
     }
 
@@ -767,7 +778,8 @@ __device__ __forceinline__ prf_lds_cu4 *slot_after(prf_lds_cu4 *first, int a) {
 // (stride 2 / 4, and every task of a mixed tile) every examined all-match group counts.  The per-size words are OR-ed over the
 // blocks and leave as records at the end of the task.  The eight sizes are computed as two halves of four, the rows of the
 // second half's last slot loaded in between: 40 row registers instead of 48, four OR chains interleaved.
-template <int NC, bool S1>
+// HALF: only the sizes k0 .. k0+3 (a task whose second half wants another stride, or lies beyond the largest motif size).
+template <int NC, bool S1, bool HALF>
 __device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, int lane, u32 k0, u32 valid, u32 stride, u32 allow, Emit &em) {
     constexpr int PS = RG * NC;  // slots per plane
     prf_lds_cu4 *lane_base = vimg + lane;
@@ -822,11 +834,13 @@ __device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, int lane, u32 k0, 
         load_w(std::integral_constant<int, 1>{});
         load_w(std::integral_constant<int, 2>{});
         sizes(std::integral_constant<int, 0>{});
-        load_w(std::integral_constant<int, 3>{});
-        sizes(std::integral_constant<int, 1>{});
+        if constexpr (!HALF) {
+            load_w(std::integral_constant<int, 3>{});
+            sizes(std::integral_constant<int, 1>{});
+        }
     }
     const u32 sc = stride == 1 ? 1u : (stride == 2 ? 2u : 3u);
-    static_for<0, 8>([&](auto kc) {
+    static_for<0, (HALF ? 4 : 8)>([&](auto kc) {
         constexpr int kk = decltype(kc)::value;
         if ((valid >> kk) & 1u) em.push_word(acc[kk] & allow, k0 + (u32)kk, sc);  // wave-uniform condition
     });
@@ -916,6 +930,95 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
     return hot;
 }
 
+// ---- the same question answered more coarsely for M >= 7: rows in aligned groups of G = 2 (M <= 10) or 4 ----
+// A run of >= M matching rows holds C = floor((M + 1) / G) - 1 consecutive aligned groups of G rows that match throughout:
+// the first of them, group j0 = ceil(a / G), follows a group that does not (it holds row a - 1).  So the stream is
+// flagged if, for some j in 0 .. T/G, the groups j .. j+C-1 all match and group j-1 does not.  j = T/G -- the first group of the
+// NEXT stream -- is included because the run's first row may be one of the last G - 1 rows of this stream (the next stream's
+// lane flags itself for the same group: a false flag there, which costs a look and nothing else).  Two operations per row
+// for the groups' ORs, two or three per group for window and flag: 106 - 135 operations per task instead of 200 - 250; the price
+// is false flags where G C rows match by chance without M doing so (6 rows: 8 per tile and motif size on random sequence,
+// 8 rows: 0.5) -- the verification re-derives the run starts exactly either way (win_verify_flag uses M itself).
+// relax (mixed tile): also "the groups 0 .. C-1 match", which with the rule above is "some C matching groups begin here".
+template <int K, int M, int NC>
+__device__ __attribute__((noinline)) u32 coarse_stream(prf_lds_cu4 *vimg, int lane, bool relax) {
+    constexpr int PS = RG * NC;
+    constexpr int G = M >= 11 ? 4 : 2, C = (M + 1) / G - 1;
+    constexpr int NJ = T / G + 1;                   // windows j = 0 .. T/G
+    constexpr int NGRP = NJ + C;                    // groups -1 .. T/G + C - 1, stored at index + 1
+    constexpr int NR = T + G * C;                   // mismatch rows -G .. NR - 1
+    constexpr int NG = (NR + K + 3) / 4;            // 16-byte slots of rows read
+    static_assert(C >= 2 && 4 * NG <= 2 * T, "a coarse task reads its own lane and the next one");
+    prf_lds_cu4 *lane_base = vimg + lane;
+    // rows -4 .. -1: the last slot of the previous stream, (lane-1, b); for lane 0 that is stream (63, b-1): lane 63's words one
+    // bit up, with bit 0 (the previous tile's last stream) unknown -> "mismatch", verification decides
+    u32 q0[4], q1[4];
+    {
+        const int pl = (lane + 63) & 63;
+        prf_lds_cu4 *pp = vimg + pl + (RG - 1) * NC;
+        prf_u32x4 v0 = pp[0], v1 = pp[PS];
+        if (lane == 0) {
+            v0 <<= 1;
+            v1 <<= 1;
+        }
+        q0[0] = v0.x; q0[1] = v0.y; q0[2] = v0.z; q0[3] = v0.w;
+        q1[0] = v1.x; q1[1] = v1.y; q1[2] = v1.z; q1[3] = v1.w;
+    }
+    u32 r0[4 * NG], r1[4 * NG];
+    u32 grp[NGRP];
+    u32 hot = 0;
+    auto load_slot = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < NG) {
+            prf_lds_cu4 *ps = slot_of<NC>(lane_base, g);
+            const prf_u32x4 v0 = ps[0], v1 = ps[PS];
+            r0[4 * g] = v0.x; r0[4 * g + 1] = v0.y; r0[4 * g + 2] = v0.z; r0[4 * g + 3] = v0.w;
+            r1[4 * g] = v1.x; r1[4 * g + 1] = v1.y; r1[4 * g + 2] = v1.z; r1[4 * g + 3] = v1.w;
+        }
+    };
+    // row r of plane p, r >= -4 (compile-time r)
+    auto h = [&](auto rc) -> u32 { constexpr int r = decltype(rc)::value; if constexpr (r < 0) return q0[r + 4]; else return r0[r]; };
+    auto l = [&](auto rc) -> u32 { constexpr int r = decltype(rc)::value; if constexpr (r < 0) return q1[r + 4]; else return r1[r]; };
+    load_slot(std::integral_constant<int, 0>{});
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        load_slot(std::integral_constant<int, g + 1>{});  // one slot ahead of the rows that are computed
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto jc) {
+            constexpr int i = 4 * g + decltype(jc)::value - K;  // the mismatch row whose partner row has just arrived
+            // the last row of group j = (i + 1) / G - 1 (groups -1 .. NGRP - 2): the whole group is there now
+            if constexpr (i >= -1 && i < NR && (i + 1) % G == 0) {
+                constexpr int j = (i + 1) / G - 1, first = G * j;
+                u32 t = h(std::integral_constant<int, first>{}) ^ h(std::integral_constant<int, first + K>{});
+                t = or_xor(t, l(std::integral_constant<int, first>{}), l(std::integral_constant<int, first + K>{}));
+                static_for<1, G>([&](auto ic) {
+                    constexpr int r = first + decltype(ic)::value;
+                    t = or_xor(t, h(std::integral_constant<int, r>{}), h(std::integral_constant<int, r + K>{}));
+                    t = or_xor(t, l(std::integral_constant<int, r>{}), l(std::integral_constant<int, r + K>{}));
+                });
+                if constexpr (j == -1) {
+                    if (lane == 0) t |= 1u;
+                }
+                grp[j + 1] = t;
+                constexpr int w = j - C + 1;  // the window whose last group this is
+                if constexpr (w >= 0 && w < NJ) {
+                    u32 win;
+                    if constexpr (C == 2) win = grp[w + 1] | grp[w + 2];
+                    else if constexpr (C == 3) win = or3(grp[w + 1], grp[w + 2], grp[w + 3]);
+                    else if constexpr (C == 4) win = or3(grp[w + 1], grp[w + 2], grp[w + 3]) | grp[w + 4];
+                    else win = or3(or3(grp[w + 1], grp[w + 2], grp[w + 3]), grp[w + 4], grp[w + 5]);
+                    static_assert(C <= 5, "window of at most five groups");
+                    hot = bitop3<(TA | (~TB & TC)) & 0xFF>(hot, win, grp[w]);  // hot | (~win & group w-1)
+                    if constexpr (w == 0) {
+                        if (relax) hot |= ~win;
+                    }
+                }
+            }
+        });
+    });
+    return hot;
+}
+
 // The (K, M) variants, K <= M < SMALL_M, numbered densely in (K, M) order; the dispatch is a binary search over that number
 // (7 wave-uniform branches; a chain of `if (k == K)` tests cost a task about thirty taken branches).
 constexpr int exact_variants() { return (SMALL_M - 1) * SMALL_M / 2; }
@@ -930,7 +1033,8 @@ __device__ __forceinline__ u32 exact_dispatch(prf_lds_cu4 *vimg, int lane, bool 
     if constexpr (LO == HI) {
         constexpr int K = exact_variant_k(LO), M = K + (LO - exact_variant_of(K, K));
         static_assert(M >= K && M < SMALL_M && exact_variant_of(K, M) == LO, "variant numbering");
-        return exact_stream<K, M, NC>(vimg, lane, relax);
+        if constexpr (M >= 7) return coarse_stream<K, M, NC>(vimg, lane, relax);
+        else return exact_stream<K, M, NC>(vimg, lane, relax);
     } else {
         constexpr int MID = (LO + HI) / 2;
         if (v <= (u32)MID) return exact_dispatch<LO, MID, NC>(vimg, lane, relax, v);  // wave-uniform
@@ -959,8 +1063,14 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, 
         if (dbg && lane == 0 && ti - plan.wave_begin[wave] < 8u) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
 #endif
         if (task.kind == 0) {
-            if (task.stride == 1 && !relax) group_task<NC, true>(vimg, lane, task.k0, task.valid, 1u, allow, em);
-            else group_task<NC, false>(vimg, lane, task.k0, task.valid, task.stride, allow, em);
+            const bool half = (task.valid & 0xF0u) == 0;
+            if (task.stride == 1 && !relax) {
+                if (half) group_task<NC, true, true>(vimg, lane, task.k0, task.valid, 1u, allow, em);
+                else group_task<NC, true, false>(vimg, lane, task.k0, task.valid, 1u, allow, em);
+            } else {
+                if (half) group_task<NC, false, true>(vimg, lane, task.k0, task.valid, task.stride, allow, em);
+                else group_task<NC, false, false>(vimg, lane, task.k0, task.valid, task.stride, allow, em);
+            }
         } else {
 #ifdef PRF_STAMPS
             const u64 tc0 = __builtin_amdgcn_s_memtime();

@@ -48,7 +48,9 @@ def test_default_parameters():
     plan = check(1, 50, 3, 9)
     assert plan["waves"] == 4
     strides = {t["k0"]: t["stride"] for t in plan["tasks"] if t["kind"] == 0}
-    assert strides == {8: 1, 16: 2, 24: 4, 32: 4, 40: 4, 48: 4}
+    # (round 3: a task may take four sizes only, so that 12-15 are examined at every 2nd group and 20-23 at every 4th)
+    assert strides == {8: 1, 12: 2, 20: 4, 28: 4, 36: 4, 44: 4}
+    assert {t["k0"]: t["valid"] for t in plan["tasks"] if t["kind"] == 0} == {8: 0x0F, 12: 0xFF, 20: 0xFF, 28: 0xFF, 36: 0xFF, 44: 0x7F}
     assert sorted(t["k0"] for t in plan["tasks"] if t["kind"]) == [1, 2, 3, 4, 5, 6, 7]
 
 
