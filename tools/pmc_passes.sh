@@ -16,6 +16,7 @@ rocprofv3 --output-format csv --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/fetch" -o run -- python3 bench.py "${args[@]}" > "$out/fetch.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/write" -o run -- python3 bench.py "${args[@]}" > "$out/write.log" 2>&1
 python3 tools/pmc_summary.py prf_vscan "$out/pmc.json" "$out/sq1" "$out/sq2" "$out/fetch" "$out/write" > /dev/null
+python3 tools/pmc_summary.py prf_vgather "$out/pmc_gather.json" "$out/sq1" "$out/sq2" "$out/fetch" "$out/write" > /dev/null
 find "$out/kt" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
 cat "$out/pmc.json"
 head -5 "$out/kernel_stats.csv"
