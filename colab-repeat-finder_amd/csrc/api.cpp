@@ -548,6 +548,10 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
     a.tile_info = g->d_tile_info;
     a.counters = c->d_vcounters + (size_t)c->parity * PRF_CNT_N;
     a.dbg = nullptr;
+    {
+        static const u32 skip_env = getenv("PRF_SKIP") ? (u32)strtoul(getenv("PRF_SKIP"), nullptr, 0) : 0u;  // diagnostic: wrong rows, timing only
+        a.skip = skip_env;
+    }
 #ifdef PRF_STAMPS
     {
         static u64 *dbg_buf = nullptr;

@@ -34,8 +34,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.stride = 1;
             // measured (stamps build, 6 workgroups per CU, units of 10 cycles): 4.9 k cycles for M <= 6 (one operation per
             // window), 5.4 k for M = 7 .. 9 (two), 6.0 k from M = 10 on (more rows of the next lane)
-            // (from M = 7 on the task works on groups of rows, coarse_stream: 130 - 155 operations instead of 200 - 250)
-            it.cost = M <= 6 ? 490u : (M <= 8 ? 360u : (M <= 10 ? 400u : 350u));
+            // measured on the final kernel (stamps build, 6 workgroups per CU, units of 10 cycles): 6.6 k cycles for the exact form
+            // (M <= 6), 4.6 - 5.2 k for groups of 2 rows (M 7 - 10), 4.0 k for groups of 4 (M >= 11)
+            it.cost = M <= 6 ? 660u : (M <= 8 ? 470u : (M <= 10 ? 520u : 400u));
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {
@@ -66,9 +67,9 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             it.t.stride = (unsigned char)stride;
             // measured (units of 10 cycles): 10.5 k / 5.1 k / 4.2 k cycles with 8 sizes, 2.2 k for stride 4 with 3; a task of four
             // sizes reads three quarters of the rows of one of eight
+            // measured: stride 1 with 4 sizes 6.5 k cycles, stride 2 with 8 sizes 8.3 k, stride 4 with 8 / 7 sizes 4.4 - 4.9 k / 4.2 k
             const u32 n_sizes = (u32)__builtin_popcount(valid);
-            it.cost = stride == 1 ? 250u + 100u * n_sizes : (stride == 2 ? 110u + 50u * n_sizes : 100u + 40u * n_sizes);
-            if (half) it.cost += stride == 1 ? 130u : (stride == 2 ? 60u : 40u);
+            it.cost = stride == 1 ? 155u + 125u * n_sizes : (stride == 2 ? 105u + 90u * n_sizes : 140u + 40u * n_sizes);
             items.push_back(it);
             reach = std::max<u32>(reach, 24 + k0 + (half ? 11 : 15));
             covered_to = k0 + (half ? 4 : 8);

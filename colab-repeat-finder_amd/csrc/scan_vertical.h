@@ -47,6 +47,7 @@ struct prf_vscan_args {
     const uint4 *tile_info;        // [tile]: {contig, 0, contig base lo, hi}
     u64 *counters;                 // this scan's counter block (zero when the kernel starts)
     u64 *dbg;                      // diagnostic (PRF_STAMPS) builds only; nullptr otherwise
+    u32 skip;                      // diagnostic (PRF_SKIP): phases left out to time the others; 0 in every real scan
     prf_vplan plan;
 };
 

@@ -1234,6 +1234,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     prf_lds_u32 *next_words = (prf_lds_u32 *)(prf_smem + HDR_NEXT);  // {next slot, its launch-list entry}
     u32 slot_next = 0;
     u32 parity = 0;
+    u64 cand_total = 0;  // (thread 0) candidates looked at by this workgroup: ONE atomic when it ends
     for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next, parity ^= 1u) {
     // (opaque per round: what derives from the thread index is recomputed, not carried through the scan's calls in
     // registers that would have to be spilled)
@@ -1296,27 +1297,53 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     u64 *task_dbg = nullptr;
 #endif
     {
-        const u32 allow = hasx ? ~nostart[lane] : ~0u;
+        u32 allow = hasx ? ~nostart[lane] : ~0u;
+        if (g.skip & 1u) allow = 0u;  // (diagnostic, PRF_SKIP: no flags, no records)
         run_tasks<NC>((prf_lds_cu4 *)vimg, hotw, g.plan, wave, lane, hasx, allow, em, task_dbg);
+    }
+    // ---- 3a. R1 <- the window of the linear planes H and L (tile - 128 .. tile + 65536 + 1536 positions), in 16-byte units: unit
+    // u < LW/2 is H's word pair u, the others L's; piece = 64 units = 1 KiB.  R1 is the image until the LAST wave has finished its
+    // tasks, so the window cannot be sent there earlier -- but the waves do not finish together (18.7 - 22.2 k cycles): the first
+    // two to arrive load the window into registers (9 and 8 pieces: 36 / 32 VGPRs, free at this point) while they would
+    // otherwise wait at the barrier, and store it behind the barrier.  The first version sent it by DMA behind the barrier: 2 - 4 k
+    // cycles of HBM latency with every wave waiting.
+    constexpr u32 WIN_UNITS = (u32)LW;  // 2 planes x LW / 2
+    constexpr u32 WIN_PIECES = (WIN_UNITS + 63u) / 64u;
+    static_assert(WIN_PIECES == 17, "the window's pieces are dealt 9 + 8 to the first two waves to arrive");
+    prf_u32x4 wv[9];
+    u32 order = 0;
+    {
+        if (lane == 0) order = atomicAdd((u32 *)(cnt + CNT_ROWS0), 1u);  // (the counter is free until the barrier: arrival order)
+        order = (u32)__builtin_amdgcn_readfirstlane((int)order);
+        const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;
+        const u64 *wh = g.H + w0, *wl = g.L + w0;
+        const prf_u32x4 z = {0, 0, 0, 0};
+        static_for<0, 9>([&](auto ic) { wv[decltype(ic)::value] = z; });
+        if (order < 2u) {
+            const u32 first = order * 9u, n = order ? 8u : 9u;
+            static_for<0, 9>([&](auto ic) {
+                constexpr u32 i = (u32)decltype(ic)::value;
+                if (i < n) {  // wave-uniform
+                    const u32 u = (first + i) * 64u + (u32)lane;
+                    const u64 *src = u < (u32)LW / 2u ? wh + 2u * u : wl + 2u * (u - (u32)LW / 2u);
+                    if (u < WIN_UNITS) wv[i] = *reinterpret_cast<const prf_u32x4 *>(src);
+                }
+            });
+        }
     }
     PRF_STAMP(3);
     __syncthreads();  // the image is dead from here on
-    // ---- 3a. R1 <- the window of the linear planes H and L (tile - 128 .. tile + 65536 + 1536 positions) by DMA, in 16-byte
-    // units: unit u < LW/2 is H's word pair u, the others L's; piece = 64 units = 1 KiB; piece i of wave w is w + 4 i.
     {
-        const long long w0 = (long long)(tile * PRF_TILE_WORDS) - LIN_PRE;
-        const u64 *wh = g.H + w0, *wl = g.L + w0;
-        constexpr u32 UNITS = (u32)LW;  // 2 planes x LW / 2
-        constexpr u32 PIECES = (UNITS + 63u) / 64u;
-        static_for<0, 5>([&](auto ic) {
-            constexpr u32 i = (u32)decltype(ic)::value;
-            const u32 piece = (u32)wave + 4u * i;
-            if (piece < PIECES) {  // wave-uniform
-                const u32 u = piece * 64u + (u32)lane;
-                const u64 *src = u < (u32)LW / 2u ? wh + 2u * u : wl + 2u * (u - (u32)LW / 2u);
-                if (u < UNITS) dma16(src, R1_OFF + piece * 1024u);
-            }
-        });
+        if (order < 2u) {
+            const u32 first = order * 9u, n = order ? 8u : 9u;
+            static_for<0, 9>([&](auto ic) {
+                constexpr u32 i = (u32)decltype(ic)::value;
+                if (i < n) {
+                    const u32 u = (first + i) * 64u + (u32)lane;
+                    if (u < WIN_UNITS) *(prf_lds_u4 *)(prf_smem + R1_OFF + 16u * u) = wv[i];
+                }
+            });
+        }
         // the row list is padded to its capacity with the largest key: no bounds test per key when the rows are ranked
         // (rows that the scan's overflow paths have listed already stay; the verification appends behind them)
         const u32 n0 = cnt[CNT_ROWS];
@@ -1328,7 +1355,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             cnt[CNT_LONG0] = cnt[CNT_LONG];
         }
     }
-    __syncthreads();  // (waits for the window's DMA too)
+    __syncthreads();
     PRF_STAMP(4);
 
     // ---- 3b. verify, all waves together: every candidate -> a row in the tile's list, or nothing ----
@@ -1340,13 +1367,13 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     {
         if (tid == 0) {
             // statistics: candidates looked at = (stream, exact task) flags + group-task records (+ those verified on the spot)
-            const u32 n_cand = n_flags + n_recs + cnt[CNT_EARLY];
-            if (n_cand)
-                atomicAdd(&g.counters[PRF_CNT_SHARD0 + (tile % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], (u64)n_cand);
+            cand_total += n_flags + n_recs + cnt[CNT_EARLY];
         }
         n_recs = n_recs < (u32)REC_CAP ? n_recs : (u32)REC_CAP;
         n_flags = n_flags < (u32)FLAG_CAP ? n_flags : (u32)FLAG_CAP;
-        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
+        if (g.skip & 2u) n_flags = 0;   // (diagnostic) the flags are listed but not verified
+        if (g.skip & 4u) n_recs = 0;    // (diagnostic) the same for the records
+        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
     }
     set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
@@ -1382,11 +1409,20 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     const u64 nw = *(prf_lds_u64 *)next_words;  // (one read)
     slot_next = (u32)__builtin_amdgcn_readfirstlane((int)(u32)nw);
     const u32 entry_next = (u32)(nw >> 32);
-    const u32 n_rows = (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_ROWS]);
+    const u32 n_rows = (g.skip & 16u) ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_ROWS]);  // (diagnostic: rows counted as none)
     const u32 n_long = (u32)__builtin_amdgcn_readfirstlane((int)cnt[CNT_LONG]);
     u64 *slab = g.slabs + (u64)slot * g.slab_cap;
     const u32 n_store = n_rows < g.slab_cap ? n_rows : g.slab_cap;
     bool unsorted = false;
+    // The tile's row count, and its share of the sum the gather kernel starts from, leave NOW: a device-scope atomic stays
+    // outstanding for ~3 k cycles when every CU issues them, and the tile's last barrier waits for it.  Issued behind the
+    // ranking (first version) that wait was exposed: 7 % of the scan on the default workload, 27 % on random sequence
+    // (PRF_SKIP=32, profiles/r03_notes.md); here it hides behind the rows phase.  ONE atomic per tile (the second level of sums
+    // is gone: the gather adds the first level up itself).
+    if (tid == 0) {
+        g.slab_count[slot] = n_rows;
+        if (n_store && !(g.skip & 32u)) atomicAdd(&g.block_sum[slot >> g.gather_shift], n_store);
+    }
 
     // ---- 4. the tile's rows, sorted by (start, end), into its slab.  Rank of a row = number of rows with a smaller key; keys
     // are distinct ((start, end) pairs never collide between motif sizes).
@@ -1470,17 +1506,12 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             if (P >= 2u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0xB1, 0xF, 0xF, true);
             if (P >= 4u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x4E, 0xF, 0xF, true);
             if (P >= 8u) rank += (u32)__builtin_amdgcn_update_dpp(0, (int)rank, 0x141, 0xF, 0xF, true);
-            if (row < n_rows && part == 0 && rank < g.slab_cap) slab[rank] = (u64)mine | ((u64)kv << 32);
+            if (row < n_rows && part == 0 && rank < g.slab_cap && !(g.skip & 64u)) slab[rank] = (u64)mine | ((u64)kv << 32);
         }
     }
     if ((u32)tid < n_long && (u32)tid < PRF_LONG_PER_TILE)
         g.long_ends[(u64)slot * PRF_LONG_PER_TILE + (u32)tid] = ((prf_lds_u64 *)(prf_smem + HDR_LONG))[tid];
     if (tid == 0) {
-        g.slab_count[slot] = n_rows;
-        if (n_store) {  // rows in front of a gather workgroup's slots: two levels of sums
-            atomicAdd(&g.block_sum[slot >> g.gather_shift], n_store);
-            atomicAdd(&g.block_sum[g.super_off + ((slot >> g.gather_shift) / PRF_GATHER_SUPER)], n_store);
-        }
         if (n_rows > g.slab_cap) atomicMax(&g.counters[PRF_CNT_HIT_OVF], (u64)n_rows);
         if (unsorted) atomicMax(&g.counters[PRF_CNT_UNSORTED], 1ull);
         if (n_long > PRF_LONG_PER_TILE) atomicMax(&g.counters[PRF_CNT_LONG_OVF], (u64)n_long);
@@ -1491,6 +1522,8 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
 #endif
     // (no barrier here: the next round's first barrier separates this tile's reads of the row list from the next tile's writes)
     }
+    if (tid0 == 0 && cand_total)
+        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], cand_total);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1512,9 +1545,8 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) .. 64
     const u32 first = blockIdx.x << g.gather_shift;
     const u32 my_super = blockIdx.x / PRF_GATHER_SUPER;
-    u64 before = 0;
-    for (u32 i = tid; i < my_super; i += 256u) before += g.block_sum[g.super_off + i];
-    if (tid < blockIdx.x - my_super * PRF_GATHER_SUPER) before += g.block_sum[my_super * PRF_GATHER_SUPER + tid];
+    u64 before = 0;  // rows in front of this workgroup's slots: the sums of the workgroups before it (one atomic per tile in the scan)
+    for (u32 i = tid; i < blockIdx.x; i += 256u) before += g.block_sum[i];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
     if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel), the slots' tiles and contigs
