@@ -87,7 +87,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
     // a wave without tasks, if there is one.  (Tried and dropped: the waves of a workgroup pulling tasks from one list
     // through an LDS counter at run time -- every wave's scan got 2-3 k cycles longer; the stride-1 group task cut in two
     // halves of four sizes -- a half costs three quarters of the whole, its four blocks are LDS latency, not arithmetic.)
-    constexpr u32 TICKET_COST = 300;
+    constexpr u32 TICKET_COST = 30;  // (round 3: the atomic's value is no longer waited for on the spot)
     bool ticket_dealt = nw < (u32)PRF_VMAX_WAVES;
     plan->ticket_wave = nw < (u32)PRF_VMAX_WAVES ? nw : 0;
     for (const Item &it : sorted) {

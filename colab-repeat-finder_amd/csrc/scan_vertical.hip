@@ -1278,9 +1278,9 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     PRF_STAMP(1);
     __syncthreads();  // (waits for the image's DMA too)
     PRF_STAMP(2);
-    // the ticket for the tile after this one: drawn here, used before the last barrier of the tile.  The compiler turns the
-    // returning atomic into a wave-aggregated one and waits for its value on the spot: the plan deals it to the wave
-    // with the least other work.
+    // the ticket for the tile after this one: drawn here, first used behind the scan (round 3: the file is built with the
+    // compiler's atomic optimizer off -- it turned this one-lane returning atomic into a wave-aggregated one and waited for its
+    // value on the spot, 3 k cycles in front of the ticket wave's tasks; now the value is back long before it is looked at).
     u64 ticket = 0;
     const bool ticket_thread = tid == (int)(g.plan.ticket_wave * 64u);  // (the plan's least loaded wave)
     if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
@@ -1355,6 +1355,13 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             cnt[CNT_LONG0] = cnt[CNT_LONG];
         }
     }
+    // the next launch slot and its entry (a load from the launch list unless the list is one run of clean tiles): issued here,
+    // needed behind the verification
+    u32 slot_pre = 0, entry_pre = entry;
+    if (ticket_thread) {
+        slot_pre = (first_ticket + (u32)ticket) * 8u + xcd;
+        if (slot_pre < g.n_launch) entry_pre = entry_of(slot_pre);  // (last round: this tile again, unused)
+    }
     __syncthreads();
     PRF_STAMP(4);
 
@@ -1377,9 +1384,8 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     }
     set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
-        const u32 sn = (first_ticket + (u32)ticket) * 8u + xcd;
-        next_words[0] = sn;
-        next_words[1] = sn < g.n_launch ? entry_of(sn) : entry;  // (last round: this tile again, unused)
+        next_words[0] = slot_pre;
+        next_words[1] = entry_pre;
     }
     PRF_STAMP(5);
     __syncthreads();
