@@ -244,6 +244,10 @@ def main():
     ap.add_argument("--generic", action="store_true", help="force the generic kernel")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N=1: wait for every scan before the next is enqueued (default: two scans in flight)")
+    ap.add_argument("--preroll-ms", type=float, default=300.0,
+                    help="untimed back-to-back scans in front of the W warmup steps, until this much wall time has passed: the chip "
+                         "raises its clock over the first tens of milliseconds of sustained load (DVFS) and the scan is VALU-bound -- "
+                         "per-step kernel time falls from 0.66 to 0.53 ms over 40 steps from an idle GPU.  0: none")
     ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the rows to rank 0 every this many steps (0: never)")
     args = ap.parse_args()
     if not args.kmax:
@@ -402,6 +406,17 @@ def main():
         assert all(int(st.n_hits) == n_rows_local for st in out)
         return out
 
+    # clock ramp (see --preroll-ms): the same steps as the timed ones, untimed, until the GPU has been busy for a while
+    preroll_steps = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        if pipelined:
+            run_pipelined(8)
+        else:
+            for _ in range(8):
+                step()
+        preroll_steps += 8
+    preroll_ms = (time.perf_counter() - t_pre) * 1e3
     if pipelined:
         run_pipelined(args.warmup)
     else:
@@ -486,6 +501,9 @@ def main():
                        "rows_sha256_rank0": rows_sha256, "launches_of_the_untimed_scan": int(st0.n_launches),
                        "candidate_records_rank0": int(st0.n_candidates),
                        "steps_in_flight": 2 if pipelined else 1,
+                       "clock_ramp": {"untimed_steps_before_warmup": preroll_steps, "ms": round(preroll_ms, 1),
+                                      "why": "DVFS: from an idle GPU the per-step kernel time falls for the first ~40 back-to-back steps "
+                                             "(roofline.kernel_ms_per_step shows what is left of that); --preroll-ms 0 turns it off"},
                        # what the host adds to a step beyond the slowest rank's two kernels (launches, polling, hand-off to the gather)
                        "host_overhead_ms_per_step": round(ms_per_step - both_ms_max, 5),
                        "multi_gpu": ({"sharding": "every rank holds the genome and scans its share of the tiles (prf_genome_select); "
@@ -506,6 +524,7 @@ def main():
                          "t_scan_ms": round(t_scan, 5),
                          "kernel_ms": round(p1, 5),
                          "kernel_ms_min_median": [round(float(np.min(scan_ms)), 5), round(float(np.median(scan_ms)), 5)] if scan_ms is not None else None,
+                         "kernel_ms_per_step": [round(float(x), 4) for x in scan_ms] if scan_ms is not None else None,
                          "gather_kernel_ms": round(float(np.mean(gather_kernel_ms)), 5) if gather_kernel_ms is not None else None,
                          "scan_kernel_only": {"achieved": round(achieved_scan_only, 2), "frac": round(achieved_scan_only / HBM_PEAK_GBPS, 5)},
                          "algorithmic_bytes_per_launch": bytes_alg,
