@@ -706,10 +706,13 @@ static int scan_impl(prf_ctx *c, const prf_genome *g, uint32_t kmin, uint32_t km
             ncand = 0;
             for (int sh = 0; sh < PRF_CNT_NSHARD; sh++)
                 ncand += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND];
-            if (getenv("PRF_DEBUG"))
-                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu hit_ovf %llu unsorted %llu ms %.4f\n", (unsigned long long)nhits,
-                        (unsigned long long)ncand, (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF],
-                        (unsigned long long)c->h_counters[PRF_CNT_UNSORTED], ms01);
+            if (getenv("PRF_DEBUG")) {
+                u64 nearly = 0;
+                for (int sh = 0; sh < PRF_CNT_NSHARD; sh++) nearly += c->h_counters[PRF_CNT_SHARD0 + sh * PRF_CNT_SHARD_STRIDE + PRF_SH_EARLY];
+                fprintf(stderr, "[prf] fused: hits %llu cand-records %llu (verified on the spot, a list being full: %llu) hit_ovf %llu unsorted %llu ms %.4f\n",
+                        (unsigned long long)nhits, (unsigned long long)ncand, (unsigned long long)nearly,
+                        (unsigned long long)c->h_counters[PRF_CNT_HIT_OVF], (unsigned long long)c->h_counters[PRF_CNT_UNSORTED], ms01);
+            }
             if (c->h_counters[PRF_CNT_LONG_OVF])
                 return fail(PRF_EHIP, "internal: a tile reported %llu rows longer than 65534 positions (at most %u can exist)",
                             (unsigned long long)c->h_counters[PRF_CNT_LONG_OVF], PRF_LONG_PER_TILE);

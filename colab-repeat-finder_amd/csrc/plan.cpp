@@ -36,7 +36,7 @@ bool prf_vertical_plan(u32 kmin, u32 kmax, u32 min_repeats, u32 min_span, prf_vp
             // window), 5.4 k for M = 7 .. 9 (two), 6.0 k from M = 10 on (more rows of the next lane)
             // measured on the final kernel (stamps build, 6 workgroups per CU, units of 10 cycles): 6.6 k cycles for the exact form
             // (M <= 6), 4.6 - 5.2 k for groups of 2 rows (M 7 - 10), 4.0 k for groups of 4 (M >= 11)
-            it.cost = M <= 6 ? 660u : (M <= 8 ? 470u : (M <= 10 ? 520u : 400u));
+            it.cost = M <= 8 ? 660u : (M <= 10 ? 520u : 400u);
             items.push_back(it);
             reach = std::max<u32>(reach, 4 * (((u32)T + (u32)M - 1 + k + 3) / 4) - 1);
         } else if (k >= covered_to) {

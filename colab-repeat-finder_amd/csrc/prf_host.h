@@ -18,6 +18,7 @@ enum {
     PRF_CNT_NSHARD = 16,
     PRF_CNT_SHARD_STRIDE = 8,
     PRF_SH_CAND = 1,
+    PRF_SH_EARLY = 4,        // fused path: candidates verified on the spot because a tile's list was full (diagnostic)
     PRF_SH_TILE_TICKET = 2,  // fused path, shards 0..7: launch slots handed out to the persistent workgroups of XCD 0..7
     PRF_CNT_LONG_OVF = 8 + 3,  // fused path (shard 0, word 3): a tile held more than PRF_LONG_PER_TILE rows with a clipped span (cannot happen)
     PRF_CNT_N = 8 + 16 * 8

@@ -930,7 +930,7 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
     return hot;
 }
 
-// ---- the same question answered more coarsely for M >= 7: rows in aligned groups of G = 2 (M <= 10) or 4 ----
+// ---- the same question answered more coarsely for M >= 9: rows in aligned groups of G = 2 (M <= 10) or 4 ----
 // A run of >= M matching rows holds C = floor((M + 1) / G) - 1 consecutive aligned groups of G rows that match throughout:
 // the first of them, group j0 = ceil(a / G), follows a group that does not (it holds row a - 1).  So the stream is
 // flagged if, for some j in 0 .. T/G, the groups j .. j+C-1 all match and group j-1 does not.  j = T/G -- the first group of the
@@ -938,7 +938,9 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
 // lane flags itself for the same group: a false flag there, which costs a look and nothing else).  Two operations per row
 // for the groups' ORs, two or three per group for window and flag: 106 - 135 operations per task instead of 200 - 250; the price
 // is false flags where G C rows match by chance without M doing so (6 rows: 8 per tile and motif size on random sequence,
-// 8 rows: 0.5) -- the verification re-derives the run starts exactly either way (win_verify_flag uses M itself).
+// 8 rows: 0.5) -- the verification re-derives the run starts exactly either way (win_verify_flag uses M itself).  M = 7 and 8
+// would get groups of 2 with C = 3: those 8 false flags per tile and motif size (52 per tile on the default workload, a third
+// pass over the flags for one wave) cost more than the 70 operations they save: they keep the exact form.
 // relax (mixed tile): also "the groups 0 .. C-1 match", which with the rule above is "some C matching groups begin here".
 template <int K, int M, int NC>
 __device__ __attribute__((noinline)) u32 coarse_stream(prf_lds_cu4 *vimg, int lane, bool relax) {
@@ -1033,7 +1035,7 @@ __device__ __forceinline__ u32 exact_dispatch(prf_lds_cu4 *vimg, int lane, bool 
     if constexpr (LO == HI) {
         constexpr int K = exact_variant_k(LO), M = K + (LO - exact_variant_of(K, K));
         static_assert(M >= K && M < SMALL_M && exact_variant_of(K, M) == LO, "variant numbering");
-        if constexpr (M >= 7) return coarse_stream<K, M, NC>(vimg, lane, relax);
+        if constexpr (M >= 9) return coarse_stream<K, M, NC>(vimg, lane, relax);  // (M = 7, 8: groups of 2 rows give 8 false flags per tile and size)
         else return exact_stream<K, M, NC>(vimg, lane, relax);
     } else {
         constexpr int MID = (LO + HI) / 2;
@@ -1235,6 +1237,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     u32 slot_next = 0;
     u32 parity = 0;
     u64 cand_total = 0;  // (thread 0) candidates looked at by this workgroup: ONE atomic when it ends
+    u64 early_total = 0; // ... of which verified on the spot by the general routine because a list was full
     for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next, parity ^= 1u) {
     // (opaque per round: what derives from the thread index is recomputed, not carried through the scan's calls in
     // registers that would have to be spilled)
@@ -1375,6 +1378,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
         if (tid == 0) {
             // statistics: candidates looked at = (stream, exact task) flags + group-task records (+ those verified on the spot)
             cand_total += n_flags + n_recs + cnt[CNT_EARLY];
+            early_total += cnt[CNT_EARLY];
         }
         n_recs = n_recs < (u32)REC_CAP ? n_recs : (u32)REC_CAP;
         n_flags = n_flags < (u32)FLAG_CAP ? n_flags : (u32)FLAG_CAP;
@@ -1530,6 +1534,8 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     }
     if (tid0 == 0 && cand_total)
         atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], cand_total);
+    if (tid0 == 0 && early_total)
+        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_EARLY], early_total);
 }
 
 // ---------------------------------------------------------------------------------------------------
