@@ -169,6 +169,9 @@ def _build_parser():
     p.add_argument("--verbose", action="store_true", help="Print verbose output.")
     p.add_argument("--debug", action="store_true", help="Print debugging output.")
     p.add_argument("--show-progress-bar", action="store_true", help="Accepted for compatibility (scans take milliseconds).")
+    p.add_argument("--stats", action="store_true",
+                   help="(not in the reference) after a whole-FASTA scan print one JSON line: positions, rows, device time of the scan, "
+                        "Gbp/s, algorithmic bytes (2 bits per position + 24 bytes per row) and GB/s")
     p.add_argument("input_sequence", help="A nucleotide sequence, or the path of a FASTA file")
     return p
 
@@ -178,8 +181,9 @@ def _scan_whole_fasta(fasta, bed_path, fs, report):
     over the contigs one detect_repeats() call at a time).  report(entry, n_rows) is called per contig in order."""
     try:
         # min_repeats == 1: prf_scan serves it contig by contig on the literal lane (N-trimming included)
-        prf_native.scan_fasta_to_bed(prf_native.default_context(), fasta, bed_path, fs.min_motif_size, fs.max_motif_size,
-                                     fs.min_repeats, fs.min_span, on_contig=report)
+        _counts, stats = prf_native.scan_fasta_to_bed(prf_native.default_context(), fasta, bed_path, fs.min_motif_size,
+                                                      fs.max_motif_size, fs.min_repeats, fs.min_span, on_contig=report)
+        return stats
     except prf_native.PrfError as exc:
         if exc.code in (prf_native.PRF_EINVAL, prf_native.PRF_ESYMBOL):
             raise ValueError(exc.message) from None
@@ -357,8 +361,17 @@ def _scan_fasta(args, parser):
             return
         entries = prf_native.Fasta(args.input_sequence)   # libprf's reader (plain or gzip); pyfastx in the reference
         _check_settings(args)
-        _scan_whole_fasta(entries, bed_path, args, report)
+        stats = _scan_whole_fasta(entries, bed_path, args, report)
         print(f"Wrote results to {bed_path}")
+        if getattr(args, "stats", False) and stats is not None:
+            import json
+            alg = int(stats.packed_bytes) + 24 * int(stats.n_hits)          # 2-bit input once for all k + the rows
+            ms = float(stats.scan_ms)
+            print(json.dumps({"positions": int(stats.positions), "rows": int(stats.n_hits), "scan_ms": round(ms, 4),
+                              "Gbp_per_s": round(int(stats.positions) / ms / 1e6, 2) if ms else None,
+                              "algorithmic_bytes": alg, "algorithmic_GB_per_s": round(alg / ms / 1e6, 2) if ms else None,
+                              "kernel_path": ["generic", "fused", "literal"][int(stats.path)],
+                              "rows_sorted_on_device": bool(stats.sorted_on_device), "kernel_launches": int(stats.n_launches)}))
         return
     parts = re.split("[:-]", args.interval)
     if len(parts) != 3:
