@@ -1382,6 +1382,9 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
         }
         n_recs = n_recs < (u32)REC_CAP ? n_recs : (u32)REC_CAP;
         n_flags = n_flags < (u32)FLAG_CAP ? n_flags : (u32)FLAG_CAP;
+#ifdef PRF_STAMPS
+        if (g.dbg && tid == 0) g.dbg[((u64)slot * MAX_WAVES + 0) * 16 + 11] = (u64)n_flags | ((u64)n_recs << 32);  // (wave 0 has three tasks)
+#endif
         if (g.skip & 2u) n_flags = 0;   // (diagnostic) the flags are listed but not verified
         if (g.skip & 4u) n_recs = 0;    // (diagnostic) the same for the records
         verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
@@ -1553,6 +1556,8 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     __shared__ u32 contig[PRF_GATHER_SLOTS_MAX];
     __shared__ u64 ticket_lds;
     __shared__ u64 stage[2 * 3 * 256];
+    __shared__ u32 fix_n;                                               // rows whose span is clipped: their true ends are filled in
+    __shared__ u64 fix[PRF_GATHER_SLOTS_MAX * PRF_LONG_PER_TILE];       // behind the copy (row | slot << 32 | index of the end << 40)
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) .. 64
     const u32 first = blockIdx.x << g.gather_shift;
@@ -1561,6 +1566,7 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     for (u32 i = tid; i < blockIdx.x; i += 256u) before += g.block_sum[i];
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
+    if (tid == 0) fix_n = 0;
     if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel), the slots' tiles and contigs
         const bool live = tid < n_slots && first + tid < g.n_launch;
         u32 c = live ? g.slab_count[first + tid] : 0u;
@@ -1587,52 +1593,88 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     const u64 room_rows = base0 < g.rows_cap ? g.rows_cap - base0 : 0;
     const u32 n_copy = (u64)n_mine < room_rows ? n_mine : (u32)room_rows;  // rows
     u64 *dst = reinterpret_cast<u64 *>(g.rows + base0);
-    // 256 rows per round: thread t decodes row r0 + t into three words in LDS, then the 768 words leave as coalesced stores.  Two
-    // staging buffers used alternately -- one barrier per round -- and the next round's slab row is fetched (slot search + load)
-    // before this round's stores are issued.
-    auto fetch = [&](u32 row, u32 &lo_out) -> u64 {
-        u32 lo = 0, hi = n_slots;  // the slot that holds the row: offs[lo] <= row < offs[lo + 1]
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (offs[mid] <= row) lo = mid; else hi = mid;
-        }
-        lo_out = lo;
-        return g.slabs[(u64)(first + lo) * g.slab_cap + (row - offs[lo])];
-    };
-    u32 lo = 0, buf = 0;
-    u64 sr = tid < n_copy ? fetch(tid, lo) : 0ull;
-    for (u32 r0 = 0; r0 < n_copy; r0 += 256u) {
-        u64 *st = stage + buf * 768u;
-        if (r0 + tid < n_copy) {
-            const u32 key = (u32)sr, kv = (u32)(sr >> 32);
-            const u64 start = tbase[lo] + (key >> 16);
-            const u32 li = kv >> 16;  // 1 + index of the true end of a row whose span is clipped
-            const u64 end = li ? g.long_ends[(u64)(first + lo) * PRF_LONG_PER_TILE + (li - 1u)] : start + (key & 0xFFFFu);
-            st[3u * tid] = start - cbase[lo];
-            st[3u * tid + 1u] = end - cbase[lo];
-            st[3u * tid + 2u] = (u64)(kv & 0xFFFFu) | ((u64)contig[lo] << 32);
-        }
-        if (r0 + 256u + tid < n_copy) sr = fetch(r0 + 256u + tid, lo);
-        __syncthreads();
-        const u32 n_words = 3u * (n_copy - r0 < 256u ? n_copy - r0 : 256u);
-        // 16-byte stores (8-byte ones run at 0.5 - 0.7 of their rate): the round's first word alone if it sits on an odd
-        // 8-byte boundary, pairs from there on, the last word alone if one is left over
-        u64 *d = dst + 3ull * r0;
-        const u32 head = (u32)((reinterpret_cast<uintptr_t>(d) >> 3) & 1u);
-        if (tid == 0 && head) d[0] = st[0];
-        for (u32 p = tid; head + 2u * p + 1u < n_words; p += 256u) {
-            const u32 w = head + 2u * p;
-            ulonglong2 v;
-            v.x = st[w];
-            v.y = st[w + 1u];
-            *reinterpret_cast<ulonglong2 *>(d + w) = v;
-        }
-        if (tid == 1 && ((n_words - head) & 1u)) d[n_words - 1u] = st[n_words - 1u];
-        buf ^= 1u;
+    // 256 rows per round: thread t decodes row r0 + t into three words in LDS, then the 768 words leave as coalesced stores; two
+    // staging buffers used alternately, one barrier per round.  The slab rows of EIGHT rounds are fetched (slot search + load) in
+    // one batch in front of them.  gfx950 counts loads and stores on one counter and they complete out of order with respect to
+    // each other, so waiting for a load means waiting for every store issued before it: with a fetch per round every round
+    // ended with a full write round trip -- a workgroup of the default workload has 16 rounds, and 707 / 1 415 / 2 830 workgroups
+    // (32 / 16 / 8 rounds) took 66 / 49 / 60 us.  Now a workgroup waits for memory once per eight rounds: 47.5 us -- the kernel
+    // moves 183 MB in that time (3.9 TB/s, three quarters of it writes), so what is left is the copy itself.  (The rounds'
+    // barrier orders LDS only: s_waitcnt lgkmcnt(0) + s_barrier -- which is also all that __syncthreads() is on this target.)
+    constexpr u32 DEPTH = 8;
+    u32 buf = 0;
+    for (u32 R = 0; R < n_copy; R += DEPTH * 256u) {  // (n_copy is uniform: every thread takes the same barriers)
+        u64 sr[DEPTH];
+        u32 los[DEPTH];
+        static_for<0, (int)DEPTH>([&](auto jc) {
+            constexpr u32 j = (u32)decltype(jc)::value;
+            const u32 row = R + j * 256u + tid;
+            u32 lo = 0, hi = n_slots;  // the slot that holds the row: offs[lo] <= row < offs[lo + 1]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (offs[mid] <= row) lo = mid; else hi = mid;
+            }
+            los[j] = lo;
+            sr[j] = row < n_copy ? g.slabs[(u64)(first + lo) * g.slab_cap + (row - offs[lo])] : 0ull;
+        });
+        // (the ONE wait for memory of the eight rounds, outside their divergent blocks: a wait inside a block that a wave may skip
+        // does not count behind it, and the compiler would wait again -- for every store issued since -- in each round)
+        static_for<0, (int)DEPTH>([&](auto jc) {
+            u64 &x = sr[decltype(jc)::value];
+            asm volatile("" : "+v"(x));
+        });
+        static_for<0, (int)DEPTH>([&](auto jc) {
+            constexpr u32 j = (u32)decltype(jc)::value;
+            const u32 r0 = R + j * 256u;
+            if (r0 < n_copy) {
+                u64 *st = stage + buf * 768u;
+                if (r0 + tid < n_copy) {
+                    const u32 lo = los[j];
+                    const u32 key = (u32)sr[j], kv = (u32)(sr[j] >> 32);
+                    const u64 start = tbase[lo] + (key >> 16);
+                    const u32 li = kv >> 16;  // 1 + index of the true end of a row whose span is clipped (at most PRF_LONG_PER_TILE per
+                    // tile): listed, and filled in behind the copy -- a load in here, however rare, makes every round wait for memory
+                    if (li) fix[atomicAdd(&fix_n, 1u)] = (u64)(r0 + tid) | ((u64)lo << 32) | ((u64)(li - 1u) << 40);
+                    st[3u * tid] = start - cbase[lo];
+                    st[3u * tid + 1u] = start + (key & 0xFFFFu) - cbase[lo];
+                    st[3u * tid + 2u] = (u64)(kv & 0xFFFFu) | ((u64)contig[lo] << 32);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const u32 n_words = 3u * (n_copy - r0 < 256u ? n_copy - r0 : 256u);
+                // 16-byte stores (8-byte ones run at 0.5 - 0.7 of their rate): the round's first word alone if it sits on an odd
+                // 8-byte boundary, pairs from there on, the last word alone if one is left over
+                u64 *d = dst + 3ull * r0;
+                const u32 head = (u32)((reinterpret_cast<uintptr_t>(d) >> 3) & 1u);
+                if (tid == 0 && head) d[0] = st[0];
+                for (u32 p = tid; head + 2u * p + 1u < n_words; p += 256u) {
+                    const u32 w = head + 2u * p;
+                    ulonglong2 v;
+                    v.x = st[w];
+                    v.y = st[w + 1u];
+                    *reinterpret_cast<ulonglong2 *>(d + w) = v;
+                }
+                if (tid == 1 && ((n_words - head) & 1u)) d[n_words - 1u] = st[n_words - 1u];
+                buf ^= 1u;
+            }
+        });
     }
     // the workgroup of the last slots knows the total
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_mine);
-    __syncthreads();  // every wave's stores and atomics are issued; the barrier waits for outstanding memory operations
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        atomicAdd(&g.counters[PRF_CNT_ROWS], base0 + n_mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed before this thread draws the finishing ticket below
+    }
+    __syncthreads();
+    if (fix_n) {  // (uniform) the true ends of the clipped rows, over the clipped ones the rounds have stored
+        // (a barrier does not wait for stores on this target: every wave waits for its own, then they meet)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (u32 i = tid; i < fix_n; i += 256u) {
+            const u64 e = fix[i];
+            const u32 row = (u32)e, lo = (u32)(e >> 32) & 255u, li = (u32)(e >> 40);
+            dst[3ull * row + 1u] = g.long_ends[(u64)(first + lo) * PRF_LONG_PER_TILE + li] - cbase[lo];
+        }
+        __syncthreads();
+    }
     // Finishing tickets in two levels (one word takes ~90 atomics per microsecond: thousands of workgroups on ONE ticket word
     // would cost more than the copy): a ticket per 64 workgroups, and the last of each 64 draws a global one.
     const u32 n_supers = (gridDim.x - 1u) / PRF_GATHER_SUPER + 1u;
@@ -1645,8 +1687,8 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     }
     __syncthreads();
     // ---- the last workgroup hands the counter block to the host.  The counters are only ever touched
-    // by device-scope atomics, performed at the coherence point, and every workgroup's were issued in front of the
-    // barrier that precedes its ticket (s_waitcnt vmcnt(0) before s_barrier), so they precede the last ticket.  Every
+    // by device-scope atomics, performed at the coherence point, and the one this kernel adds (the row total) has been waited
+    // for by the thread that draws its workgroup's ticket, so it precedes the last ticket.  Every
     // other workgroup has read its sums by then: they are cleared for the next scan.
     if (ticket_lds == (u64)n_supers) {
         for (u32 i = tid; i < 2u * n_supers; i += 256u) g.block_sum[g.super_off + i] = 0;

@@ -985,14 +985,13 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
     assert open("repeats.tsv").read() == "start_0based\tend\tmotif\n0\t12\tCA\n"
     # --stats (not in the reference): the same BED, the reference's stdout lines, then one JSON line
     import json
-    capsys.readouterr()
+    assert "Found 1 repeats" in capsys.readouterr().out
     prf.main(["--stats", "-o", "with_stats", "toy.fasta"])
     lines = capsys.readouterr().out.strip().split("\n")
     st = json.loads(lines[-1])
     assert open("with_stats.bed").read() == want and lines[-2] == "Wrote results to with_stats.bed"
     assert st["positions"] == sum(len(v) for v in contigs.values()) and st["rows"] == want.count("\n") and st["kernel_path"] == "fused"
     assert st["algorithmic_bytes"] == (st["positions"] + 3) // 4 + 24 * st["rows"] and st["rows_sorted_on_device"] and st["scan_ms"] > 0
-    assert "Found 1 repeats" in capsys.readouterr().out
 
 
 def test_randomised_differential_stress():

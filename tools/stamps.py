@@ -43,6 +43,13 @@ for w in range(4):
         out.append(int(np.median(nxt - starts[i])))
     print('wave', w, 'task cycles', out)
 
+nf = d[:, 0, 11] & 0xFFFFFFFF; nr = d[:, 0, 11] >> 32
+print('flags per tile: mean %.1f p10 %d p50 %d p90 %d p99 %d max %d; share <=64 %.3f <=128 %.3f <=192 %.3f <=256 %.3f' % (
+    nf.mean(), *[int(np.percentile(nf, q)) for q in (10, 50, 90, 99, 100)], *[(nf <= c).mean() for c in (64, 128, 192, 256)]))
+print('records per tile: mean %.1f p10 %d p50 %d p90 %d p99 %d max %d; share <=64 %.3f <=128 %.3f <=192 %.3f' % (
+    nr.mean(), *[int(np.percentile(nr, q)) for q in (10, 50, 90, 99, 100)], *[(nr <= c).mean() for c in (64, 128, 192)]))
+import collections
+print('joint (ceil(flags/64), ceil(recs/64)) shares:', sorted(((k, round(v / len(nf), 3)) for k, v in collections.Counter(zip(((nf + 63) // 64).tolist(), ((nr + 63) // 64).tolist())).items()), key=lambda kv: -kv[1])[:12])
 for w in range(4):
     print('wave', w, 'verify: flags part %d, records / boundary part %d' % (int(np.median(d[:, w, 14] - d[:, w, 4])), int(np.median(d[:, w, 5] - d[:, w, 14]))))
 for w in range(4):
