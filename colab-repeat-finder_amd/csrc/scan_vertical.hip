@@ -1562,14 +1562,28 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     const u32 n_slots = 1u << g.gather_shift;  // launch slots per workgroup: 8 (small launches: more workgroups) .. 64
     const u32 first = blockIdx.x << g.gather_shift;
     const u32 my_super = blockIdx.x / PRF_GATHER_SUPER;
+    // The loads of the prologue are issued together: the slots' counts and tiles (-> tile table), then the sums of the workgroups
+    // in front of this one.  (One after the other they were five to six L2 round trips before the first row moved.)
+    const bool live = tid < n_slots && first + tid < g.n_launch;  // (n_slots <= 64: the first wave)
+    u32 c = 0;
+    uint4 ti = make_uint4(0, 0, 0, 0);
+    u64 tile = 0;
+    if (live) {
+        c = g.slab_count[first + tid];
+        tile = (g.flat_base != ~0u ? g.flat_base + first + tid : g.launch_list[first + tid]) & ~PRF_LAUNCH_MIXED;
+        ti = g.tile_info[tile];
+    }
     u64 before = 0;  // rows in front of this workgroup's slots: the sums of the workgroups before it (one atomic per tile in the scan)
-    for (u32 i = tid; i < blockIdx.x; i += 256u) before += g.block_sum[i];
+    for (u32 i = tid; i < blockIdx.x; i += 1024u) {  // (four independent loads per pass)
+        u32 v[4];
+#pragma unroll
+        for (u32 u = 0; u < 4u; u++) v[u] = i + 256u * u < blockIdx.x ? g.block_sum[i + 256u * u] : 0u;
+        before += (u64)v[0] + v[1] + v[2] + v[3];
+    }
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
     if (lane == 0) part[wave] = before;
     if (tid == 0) fix_n = 0;
-    if (tid < 64u) {  // exclusive scan of the counts (loaded in parallel), the slots' tiles and contigs
-        const bool live = tid < n_slots && first + tid < g.n_launch;
-        u32 c = live ? g.slab_count[first + tid] : 0u;
+    if (tid < 64u) {  // exclusive scan of the counts, the slots' tiles and contigs
         c = c < g.slab_cap ? c : g.slab_cap;
         u32 incl = c;
         for (int o = 1; o < 64; o <<= 1) {
@@ -1579,8 +1593,6 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
         offs[tid + 1] = incl;
         if (tid == 0) offs[0] = 0;
         if (live) {
-            const u64 tile = (g.flat_base != ~0u ? g.flat_base + first + tid : g.launch_list[first + tid]) & ~PRF_LAUNCH_MIXED;
-            const uint4 ti = g.tile_info[tile];
             tbase[tid] = tile * PRF_TILE;
             cbase[tid] = (u64)ti.z | ((u64)ti.w << 32);
             contig[tid] = ti.x;
