@@ -22,6 +22,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 namespace {
 
 typedef long long i64;
@@ -31,18 +33,45 @@ __device__ __forceinline__ bool lit_match(const uint8_t *__restrict__ s, i64 j, 
     return a == s[j + k] && a != 'N';  // tracker :53
 }
 
+// eight bytes from any position (two aligned dwords and a third, v_alignbyte_b32): the buffer has 16 readable bytes behind the
+// sequence, callers read from positions below L
+__device__ __forceinline__ u64 lit_load8(const uint8_t *__restrict__ s, i64 pos) {
+    const u32 *w = reinterpret_cast<const u32 *>(s + (pos & ~3ll));
+    const u32 sh = (u32)(pos & 3ll);
+    const u32 w0 = w[0], w1 = w[1], w2 = w[2];
+    return (u64)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((u64)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+}
+__device__ __forceinline__ bool lit_has_zero_byte(u64 x) { return ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0; }
+
+// "N" in s[start : start + n]   (tracker :83), eight letters per step
+__device__ __forceinline__ bool lit_has_n(const uint8_t *__restrict__ s, i64 start, i64 n) {
+    u64 any = 0;
+    for (i64 t = 0; t < n; t += 8) {
+        u64 x = lit_load8(s, start + t) ^ 0x4E4E4E4E4E4E4E4Eull;
+        const i64 rem = n - t;
+        if (rem < 8) x |= ~0ull << (8 * rem);  // letters behind the slice: never N
+        any |= (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    }
+    return any != 0;
+}
+
 // tracker :108-142: is the word a whole number (>= 2) of copies of a shorter unit?  The reference tries the units 1, 2, 3 and
 // then every divisor u >= 4 with 2u <= n by counting non-overlapping copies of the prefix; n/u copies in n letters tile the
-// word, so each branch is "the word has period u".
-__device__ bool lit_is_repeat(const uint8_t *__restrict__ m, i64 n) {
+// word, so each branch is "the word has period u".  Eight letters per comparison (round 3: byte by byte, every step a dependent
+// load, this and the N test were most of the lane's time with min_repeats == 1).
+__device__ bool lit_is_repeat(const uint8_t *__restrict__ s, i64 start, i64 n) {
     for (i64 u = 1; 2 * u <= n; u++) {
         if (n % u) continue;
         bool per = true;
-        for (i64 t = u; t < n; t++)
-            if (m[t] != m[t - u]) {
+        for (i64 t = u; t < n; t += 8) {
+            u64 x = lit_load8(s, start + t) ^ lit_load8(s, start + t - u);
+            const i64 rem = n - t;
+            if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
+            if (x) {
                 per = false;
                 break;
             }
+        }
         if (per) return true;
     }
     return false;
@@ -58,15 +87,46 @@ __global__ void prf_lit_upper_kernel(uint8_t *__restrict__ s, u64 n, u64 *__rest
     }
 }
 
+// the end of a flush call: the run [start, i] has passed both filters (or Python has raised IndexError in :87) -- the N test,
+// the primitive-motif test, the row
+// wave buffer (the 64-positions kernel): rows are collected in LDS, a wave reserves their places in the row array with ONE atomic per
+// flush -- every row drawing its own place from the one counter word was 240 k atomics on one address on 50 Mbp of random sequence,
+// 2.7 ms at the ~90 per microsecond such a word takes
+struct lit_wave_buf {
+    prf_hit_dev rows[64];
+    u32 n;
+};
+
+__device__ void lit_finish(const uint8_t *__restrict__ s, i64 L, i64 k, i64 start, i64 i, bool index_error, u32 contig,
+                           prf_hit_dev *__restrict__ rows, u64 cap, u64 *__restrict__ counters, lit_wave_buf *wb = nullptr) {
+    const i64 mlen = (start + k <= L ? start + k : L) - start;  // :82, slice clamped at the end
+    if (lit_has_n(s, start, mlen)) return;                       // :83
+    if (index_error) {
+        atomicOr(&counters[PRF_CNT_CAND], 1ull);
+        return;
+    }
+    if (lit_is_repeat(s, start, mlen)) return;                   // :98
+    // k of the row = length of the motif slice (< the tracker's k only where :82 clamped it): motif = seq[start : start + k]
+    const prf_hit_dev row{(u64)start, (u64)(i + 1), (u32)mlen, contig};
+    if (wb) {
+        const u32 at = atomicAdd(&wb->n, 1u);
+        if (at < 64u) {
+            wb->rows[at] = row;
+            return;
+        }  // (a full buffer: this row goes straight to the array; the flush takes min(n, 64))
+    }
+    const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
+    if (slot < cap) rows[slot] = row;
+}
+
 // one flush call of tracker k at position i0 (a failed comparison, or the position done() finds the tracker at)
 __device__ void lit_event(const uint8_t *__restrict__ s, i64 L, i64 k, i64 i0, u32 min_repeats, u32 min_span, u32 contig,
-                          prf_hit_dev *__restrict__ rows, u64 cap, u64 *__restrict__ counters) {
+                          prf_hit_dev *__restrict__ rows, u64 cap, u64 *__restrict__ counters, lit_wave_buf *wb = nullptr) {
     // the run that ends here: run_length - 1 matching positions directly in front of i0
     i64 start = i0;
     while (start > 0 && lit_match(s, start - 1, k)) start--;
     i64 run = i0 - start + 1;
 
-    const i64 mlen = (start + k <= L ? start + k : L) - start;  // :82, slice clamped at the end
     // :83 ("N" in motif -> return) reads up to k bytes and nearly every event fails a filter anyway, so it is evaluated
     // LAST: nothing between :83 and :98 has a side effect except the IndexError of :87, which is therefore raised only after
     // the N test has been made at that point.
@@ -87,16 +147,7 @@ __device__ void lit_event(const uint8_t *__restrict__ s, i64 L, i64 k, i64 i0, u
         }
     }
     if (!index_error && (run < (i64)min_span || run < need)) return;  // :91
-    for (i64 t = 0; t < mlen; t++)
-        if (s[start + t] == 'N') return;  // :83
-    if (index_error) {
-        atomicOr(&counters[PRF_CNT_CAND], 1ull);
-        return;
-    }
-    if (lit_is_repeat(s + start, mlen)) return;                  // :98
-    const u64 slot = atomicAdd(&counters[PRF_CNT_HITS], 1ull);
-    // k of the row = length of the motif slice (< the tracker's k only where :82 clamped it): motif = seq[start : start + k]
-    if (slot < cap) rows[slot] = prf_hit_dev{(u64)start, (u64)(i + 1), (u32)mlen, contig};
+    lit_finish(s, L, k, start, i, index_error, contig, rows, cap, counters, wb);
 }
 
 // Four positions per thread: one aligned dword of the sequence against the (unaligned) dword k bytes further on, taken from
@@ -127,6 +178,225 @@ __global__ void __launch_bounds__(256) prf_lit_events_kernel(const uint8_t *__re
         if (i0 < pos_f && ca == cb && ca != 'N') continue;  // a matching position only lengthens the run (:53-56)
         lit_event(s, L, k, i0, min_repeats, min_span, contig, rows, cap, counters);
     }
+}
+
+// ---- the same events, 64 positions per thread in registers (round 3) ----
+// The kernel above spends its time in the event routine: with min_repeats == 1 three positions in four are events, and each walks
+// back and forth over the sequence byte by byte.  Here a thread owns the 64 positions [64 B, 64 B + 64) and keeps, per motif size k
+// <= 63, two masks of them: mm (bit i: position i is a failed comparison of the tracker -- the letters differ, or the letter is N,
+// tracker :53) and pm (bit i: the letters are equal -- what the extension loop :87-89 compares, without the N rule).  The masks
+// of the 64 positions in front come from the lane below (lane 0 of a wave owns nothing: it computes the block in front of lane
+// 1's).  For an event at position i, "run length in front" is the distance to the next set bit of mm below i, and "extension" the
+// length of the row of ones of pm from i + 1 - k on, so the two filters (:86, :91) are bit arithmetic.  What the masks can
+// decide is only that an event FAILS a filter -- which is what nearly every event does; an event that passes both, or whose run or
+// extension leaves the 128 positions the thread sees, is handed to lit_event() above, which evaluates it from the bytes as
+// before.  A bit-parallel test first drops, for all 64 positions at once, every event with run < a and extension < b, where
+// (a - 1) + (b - 1) < T = max(min_span, min_repeats k): such an event cannot reach T.  Blocks near the ends of the sequence
+// (the wrap-around of :87 at the front, the clamped slice and done() at the back) go through the byte routine position by
+// position.
+__device__ __forceinline__ u32 lit_nonzero_bytes(u32 x) {  // bit t = byte t of x is not zero
+    const u32 nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    const u32 y = nz >> 7;
+    return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 15u;
+}
+// 128-bit value hi:lo shifted left / right by s in [1, 63]; the right shift fills with ones (positions past the window: unknown,
+// counted as matching so that nothing is dropped on their account)
+__device__ __forceinline__ void lit_shl(u64 &lo, u64 &hi, u32 sft) {
+    hi = (hi << sft) | (lo >> (64u - sft));
+    lo <<= sft;
+}
+__device__ __forceinline__ void lit_shr1(u64 &lo, u64 &hi, u32 sft) {
+    lo = (lo >> sft) | (hi << (64u - sft));
+    hi = (hi >> sft) | (~0ull << (64u - sft));
+}
+
+__global__ void __launch_bounds__(256) prf_lit_events64_kernel(const uint8_t *__restrict__ s, i64 L, u32 kmin, u32 n_k, u32 min_repeats,
+                                                               u32 min_span, i64 stop, u32 contig, prf_hit_dev *__restrict__ rows,
+                                                               u64 cap, u64 *__restrict__ counters, u64 wave0) {
+    __shared__ lit_wave_buf wbufs[4];
+    const u32 lane = threadIdx.x & 63u;
+    lit_wave_buf *wb = &wbufs[threadIdx.x >> 6];
+    if (lane == 0) wb->n = 0;
+    auto flush = [&]() {  // the wave's rows -> the row array: one reservation (every lane of the wave gets here together)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const u32 n_all = *(volatile u32 *)&wb->n;
+        const u32 n = n_all < 64u ? n_all : 64u;
+        u64 base = 0;
+        if (lane == 0 && n) base = atomicAdd(&counters[PRF_CNT_HITS], (u64)n);
+        base = __shfl(base, 0, 64);
+        if (lane < n && base + lane < cap) rows[base + lane] = wb->rows[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) wb->n = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    const i64 W = (i64)(wave0 + (u64)blockIdx.x * 4u + (threadIdx.x >> 6));
+    const i64 B = W * 63 + (i64)lane - 1;  // the block of 64 positions of this lane (lane 0: the one in front of lane 1's)
+    const i64 p0 = B * 64;
+    // the block's own letters, once for all motif sizes (readable: whole dwords below L + 16)
+    const bool has_a = B >= 0 && p0 + 64 <= L + 16;
+    u32 a[16];
+    u64 is_n = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = 0;
+    if (has_a) {
+        const uint4 *pa = reinterpret_cast<const uint4 *>(s + p0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 v = pa[j];
+            a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) is_n |= (u64)(lit_nonzero_bytes(a[j] ^ 0x4E4E4E4Eu) ^ 15u) << (4 * j);
+    }
+    for (u32 ki = 0; ki < n_k; ki++) {
+        const i64 k = (i64)kmin + ki;  // <= 63
+        const i64 Lk = L > k ? L - k : 0;
+        const i64 pos_f = stop < Lk ? stop : Lk;
+        const i64 T = (i64)min_span > (i64)min_repeats * k ? (i64)min_span : (i64)min_repeats * k;
+        // ---- masks of the own block: valid if every byte read lies below L + 16
+        u64 mm = 0, pm = 0;
+        const bool has_b = has_a && p0 + 64 + k + 3 < L + 16;
+        if (has_b) {
+            const u64 q = (u64)(p0 + k);
+            const u32 *w = reinterpret_cast<const u32 *>(s + (q & ~3ull));
+            const u32 sh = (u32)(q & 3ull);
+            u32 wv[17];
+#pragma unroll
+            for (int j = 0; j < 17; j++) wv[j] = w[j];
+            u64 ne = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const u32 b = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], sh);
+                ne |= (u64)lit_nonzero_bytes(a[j] ^ b) << (4 * j);
+            }
+            mm = ne | is_n;
+            pm = ~ne;
+        }
+        // the block in front: the lane below (lane 0's own value is never used: it owns nothing)
+        const u64 mm_lo = __shfl_up(mm, 1, 64), pm_lo = __shfl_up(pm, 1, 64);
+        const bool owner = !(lane == 0 || B < 0 || p0 > pos_f);
+        const bool interior = owner && B >= 1 && p0 + 128 + k <= pos_f;  // (then every byte of both blocks' masks was readable, i >= k, i < pos_f)
+        if (owner && !interior) {
+            for (int t = 0; t < 64; t++) {
+                const i64 i0 = p0 + t;
+                if (i0 > pos_f) break;
+                if (i0 < pos_f && lit_match(s, i0, k)) continue;
+                lit_event(s, L, k, i0, min_repeats, min_span, contig, rows, cap, counters, wb);
+            }
+        }
+        if (interior) {
+        // ---- all 64 positions at once: events that cannot reach T.  With run = length in front (the event's own position
+        // counted) and ext = extension: run + ext >= T implies run >= av or ext >= bv, where (av - 1) + (bv - 1) < T; and then
+        //   run >= av:  ext >= 1, or the run alone reaches T;      ext >= bv:  run >= 2, or the extension alone reaches T - 1.
+        // (Thresholds beyond the 60 positions a thread can look across are cut to that -- a weaker test, never a wrong one.)
+        u64 cand = mm;
+        if (T > 1) {
+            i64 av = T / 2 + 1;  // 2 (av - 1) >= T - 1: the "run alone" window is one more step of the same doubling
+            if (av > 60) av = 60;
+            i64 bv = T - av + 1;  // 2 bv >= T
+            if (bv > 60) bv = 60;
+            if (bv < 1) bv = 1;
+            const u32 tr = (u32)((T < 61 ? T : 61) - 1);  // matches below for "the run alone": <= 2 (av - 1)
+            const u32 te = (u32)(T - 1 < 60 ? T - 1 : 60);  // "the extension alone": <= 2 bv
+            // dn: the av - 1 positions directly below match (tracker rule); d1: the one below does; dt: tr of them do
+            u64 lo = ~mm_lo, hi = ~mm;
+            lit_shl(lo, hi, 1);  // bit n: position n - 1 matches
+            const u64 d1 = hi;
+            const u32 r = (u32)(av - 1);  // >= 1
+            u32 have = 1;
+            while (2 * have <= r) {
+                u64 l2 = lo, h2 = hi;
+                lit_shl(l2, h2, have);
+                lo &= l2; hi &= h2;
+                have *= 2;
+            }
+            if (have < r) {
+                u64 l2 = lo, h2 = hi;
+                lit_shl(l2, h2, r - have);
+                lo &= l2; hi &= h2;
+            }
+            const u64 dn = hi;
+            u64 dt = hi;
+            if (tr > r) {
+                u64 l2 = lo, h2 = hi;
+                lit_shl(l2, h2, tr - r);
+                dt = hi & h2;
+            }
+            // e1 / eb / et: 1 / bv / te equal letters from position i + 1 - k on (bit n <- bit n + 1 - k: a left shift by k - 1)
+            u64 plo = pm_lo, phi = pm;
+            u64 e1lo = plo, e1 = phi;
+            if (k > 1) lit_shl(e1lo, e1, (u32)(k - 1));
+            have = 1;
+            const u32 bb = (u32)bv;
+            while (2 * have <= bb) {
+                u64 l2 = plo, h2 = phi;
+                lit_shr1(l2, h2, have);
+                plo &= l2; phi &= h2;
+                have *= 2;
+            }
+            if (have < bb) {
+                u64 l2 = plo, h2 = phi;
+                lit_shr1(l2, h2, bb - have);
+                plo &= l2; phi &= h2;
+            }
+            u64 tlo = plo, thi = phi;
+            if (te > bb) {
+                u64 l2 = plo, h2 = phi;
+                lit_shr1(l2, h2, te - bb);
+                tlo &= l2; thi &= h2;
+            }
+            u64 eb = phi, et = thi;
+            if (k > 1) {
+                lit_shl(plo, eb, (u32)(k - 1));
+                lit_shl(tlo, et, (u32)(k - 1));
+            }
+            cand &= (dn & e1) | dt | (eb & d1) | et;
+        }
+        // ---- the events left, one by one, still in registers
+        const i64 R1 = T - k + 1;  // :86  run + k - 1 >= T
+        while (cand) {
+            const u32 i = (u32)__builtin_ctzll(cand);
+            cand &= cand - 1;
+            bool slow = false;
+            i64 run = 0;
+            const u64 below = i ? mm & ((1ull << i) - 1ull) : 0ull;
+            if (below) run = (i64)i - (63 - (i64)__builtin_clzll(below));
+            else if (mm_lo) run = (i64)i + 1 + (i64)__builtin_clzll(mm_lo);
+            else slow = true;  // the run begins in front of the 128 positions
+            if (!slow) {
+                if (run < R1) continue;  // :86 fails, and then :91 does (run <= run + k - 1 < T)
+                // extension: ones of pm from window bit m = 64 + i + 1 - k on (m >= 2)
+                const u32 m = 65u + i - (u32)k;
+                i64 ext = -1;
+                if (m < 64u) {
+                    const u64 v = ~((pm_lo >> m) | (pm << (64u - m)));
+                    if (v) ext = (i64)__builtin_ctzll(v);
+                    else {
+                        const u64 v2 = ~(pm >> m) & (~0ull >> m);
+                        if (v2) ext = 64 + (i64)__builtin_ctzll(v2);
+                    }
+                } else {
+                    const u32 m2 = m - 64u;
+                    const u64 v = m2 ? ~(pm >> m2) & (~0ull >> m2) : ~pm;
+                    if (v) ext = (i64)__builtin_ctzll(v);
+                }
+                if (ext < 0) slow = true;  // the extension reaches the end of the 128 positions
+                else if (run + ext < T) continue;  // :91
+                else {
+                    // both filters passed, run and extension known: the run is [i0 - run + 1, i0 + ext]
+                    const i64 i0 = p0 + (i64)i;
+                    lit_finish(s, L, k, i0 - run + 1, i0 + ext, false, contig, rows, cap, counters, wb);
+                    continue;
+                }
+            }
+            lit_event(s, L, k, p0 + (i64)i, min_repeats, min_span, contig, rows, cap, counters, wb);
+        }
+        }
+        // (all lanes again) a buffer half full is emptied: the next motif size may add as many rows again
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)&wb->n) >= 32u) flush();
+    }
+    flush();
 }
 
 struct lit_codes {
@@ -273,6 +543,26 @@ hipError_t prf_launch_lit_upper(hipStream_t st, uint8_t *s, u64 n, u64 *bad_pos)
 
 hipError_t prf_launch_lit_events(hipStream_t st, const uint8_t *s, u64 L, u32 kmin, u32 kmax, u32 min_repeats, u32 min_span,
                                  u64 stop, u32 contig, prf_hit_dev *rows, u64 cap, u64 *counters) {
+    // motif sizes up to 63: 64 positions per thread in registers (PRF_LIT_BYTEWISE=1: the byte routine for every size, diagnostic)
+    static const bool bytewise = getenv("PRF_LIT_BYTEWISE") && atoi(getenv("PRF_LIT_BYTEWISE")) != 0;
+    if (!bytewise && kmin <= 63u) {
+        const u32 k_hi = kmax < 63u ? kmax : 63u;
+        const u64 Lk = L > kmin ? L - kmin : 0;
+        const u64 pos_f = stop < Lk ? stop : Lk;
+        const u64 n_blocks = pos_f / 64 + 1;               // blocks 0 .. pos_f / 64 hold the positions 0 .. pos_f
+        const u64 n_waves = (n_blocks + 62) / 63;          // 63 owned blocks per wave
+        const u64 n_wg = (n_waves + 3) / 4;
+        const u64 max_wg = (1ull << 24) - 1ull;
+        for (u64 b0 = 0; b0 < n_wg; b0 += max_wg) {
+            const u64 nb = n_wg - b0 < max_wg ? n_wg - b0 : max_wg;
+            hipLaunchKernelGGL(prf_lit_events64_kernel, dim3((unsigned)nb), dim3(256), 0, st, s, (long long)L, kmin, k_hi - kmin + 1u,
+                               min_repeats, min_span, (long long)stop, contig, rows, cap, counters, b0 * 4u);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        if (kmax <= 63u) return hipSuccess;
+        kmin = 64u;
+    }
     // positions 0 .. pos_f of the smallest k cover every k
     const u64 Lk = L > kmin ? L - kmin : 0;
     const u64 n_threads = (stop < Lk ? stop : Lk) / 4 + 1;  // four positions per thread

@@ -59,8 +59,8 @@ while time.time() < t_end:
     # the literal lane (min_repeats == 1) on the same contigs through prf_scan: N-trimming, slice clamp, wrap-around, IndexError
     small = [c[:rng.choice([0, 1, 7, 300, 20000, 90000])] for c in contigs]
     kmin = rng.randint(1, 6)
-    kmax = kmin + rng.choice([0, 3, 10, 40])
-    span = rng.choice([1, 5, 9, 12, 30])
+    kmax = kmin + rng.choice([0, 3, 10, 40, 62])   # (62: across the literal lane's 63 / 64 split)
+    span = rng.choice([1, 5, 9, 12, 30, 70, 150])
     try:
         want = [(ci, a, b, ml) for ci, s in enumerate(small) for a, b, ml, _k in prf_oracle.detect_rows(s, kmin, kmax, 1, span)]
     except IndexError:
