@@ -69,6 +69,8 @@ struct prf_ctx {
     u64 *h_counters_dev = nullptr;  // device address of h_counters
     u64 *d_vcounters = nullptr;  // fused path: two counter blocks used alternately (the idle one is cleared on the device)
     u64 *d_side_cnt = nullptr;   // pipelined wire hand-off: long rows packed so far (zero between packs)
+    void *lit_scratch = nullptr;  // the literal lane's sort scratch (scan_literal.hip::prf_lit_sort_unique): kept between calls
+    size_t lit_scratch_bytes = 0;
     hipEvent_t ev_handoff = nullptr;  // prf_stream_wait_for
     u32 parity = 0;
     u64 scan_seq = 0;
@@ -209,6 +211,7 @@ void prf_close(prf_ctx *c) {
     (void)hipFree(c->d_hits_async);
     (void)hipFree(c->d_vcounters);
     (void)hipFree(c->d_side_cnt);
+    (void)hipFree(c->lit_scratch);
     if (c->ev_handoff) (void)hipEventDestroy(c->ev_handoff);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_hits);
@@ -237,7 +240,6 @@ void prf_genome_free(prf_genome *g) {
     (void)hipFree(g->d_tile_info);
     (void)hipFree(g->vp.VH);
     (void)hipFree(g->vp.VL);
-    (void)hipFree(g->vp.VX);
     (void)hipFree(g->vp.tile_class);
     (void)hipFree(g->vp.launch_list);
     (void)hipFree(g->d_sel_list);
@@ -532,7 +534,7 @@ static int launch_fused(prf_ctx *c, const prf_genome *g, const prf_vplan &plan, 
                         u64 rows_cap, u32 count_row, u64 *host_counters_dev, u64 *seq_out) {
     const launch_view lv = active_launch(g);
     prf_vscan_args a;
-    a.VH = g->vp.VH; a.VL = g->vp.VL; a.VX = g->vp.VX;
+    a.VH = g->vp.VH; a.VL = g->vp.VL;
     a.H = g->H; a.L = g->L; a.X = g->X;
     a.E = g->d_E;
     a.launch_list = lv.list; a.n_launch = lv.n; a.flat_base = lv.flat;
@@ -911,7 +913,8 @@ static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 con
                 dev_free uniq;
                 HIPCHK(hipMalloc(&uniq.p, n * sizeof(prf_hit_dev)));
                 u64 *d_n = c->d_counters + PRF_CNT_HITS;  // read above; reused for the number of rows that stay
-                HIPCHK(prf_lit_sort_unique(c->stream, (const prf_hit_dev *)rows.p, n, (prf_hit_dev *)uniq.p, d_n));
+                HIPCHK(prf_lit_sort_unique(c->stream, (const prf_hit_dev *)rows.p, n, (prf_hit_dev *)uniq.p, d_n, &c->lit_scratch,
+                                           &c->lit_scratch_bytes));
                 HIPCHK(hipMemcpyAsync(h, d_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
                 const u64 kept = h[0];
@@ -1340,6 +1343,21 @@ int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capac
     if (!g || !n_contigs || (capacity && !bases)) return fail(PRF_EINVAL, "prf_genome_contig_bases: bad arguments");
     *n_contigs = g->base.size();
     for (size_t i = 0; i < g->base.size() && i < capacity; i++) bases[i] = g->base[i];
+    return PRF_OK;
+}
+
+int prf_genome_footprint(const prf_genome *g, uint64_t *device_bytes, uint64_t *positions) {
+    if (!g || !device_bytes || !positions) return fail(PRF_EINVAL, "prf_genome_footprint: bad arguments");
+    const u64 tot = PRF_FRONT_PAD + g->nwords + g->padw;      // words of one linear plane (genome_load_impl)
+    const u64 ntiles = g->G / PRF_TILE;
+    u64 bytes = 3 * tot * 8;                                   // H, L, X
+    if (g->d_E) bytes += 5 * tot * 8 + 5 * sizeof(u64 *);      // the code planes of the letters outside ACGTN
+    bytes += 2 * ntiles * (PRF_TILE / 8);                      // VH, VL
+    bytes += 2 * ntiles + sizeof(u32) * ntiles;                // tile classes (+ scratch), launch list
+    bytes += sizeof(uint4) * ntiles + sizeof(u64) * std::max<size_t>(1, g->base.size());  // tile table, contig bases
+    if (g->d_sel_list) bytes += sizeof(u32) * std::max<size_t>(1, g->vp.h_list.size());
+    *device_bytes = bytes;
+    *positions = g->G;
     return PRF_OK;
 }
 

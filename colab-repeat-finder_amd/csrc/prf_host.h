@@ -57,4 +57,5 @@ hipError_t prf_launch_lit_trim(hipStream_t s, const u64 *X, const u64 *const *E,
 hipError_t prf_launch_lit_unpack(hipStream_t s, const u64 *H, const u64 *L, const u64 *X, const u64 *const *E, u64 g0, u64 n,
                                  uint8_t *out);
 // the rows of the event kernel sorted by (start, end) and reduced to the shortest motif per (start, end), on the device
-hipError_t prf_lit_sort_unique(hipStream_t s, const prf_hit_dev *rows, u64 n, prf_hit_dev *out, u64 *n_out);
+hipError_t prf_lit_sort_unique(hipStream_t s, const prf_hit_dev *rows, u64 n, prf_hit_dev *out, u64 *n_out, void **scratch,
+                               size_t *scratch_bytes);

@@ -490,8 +490,11 @@ __global__ void prf_lit_gather_kernel(const prf_hit_dev *__restrict__ rows, u64 
 }
 }  // namespace
 
-// rows[0..n) -> out[0..*n_out) (device memory, n_out a device word); scratch allocated and freed here (the slow lane)
-hipError_t prf_lit_sort_unique(hipStream_t st, const prf_hit_dev *rows, u64 n, prf_hit_dev *out, u64 *n_out) {
+// rows[0..n) -> out[0..*n_out) (device memory, n_out a device word).  The scratch (two key and two index arrays, the sorted rows,
+// the flags, hipCUB's own) is ONE allocation kept by the caller (*scratch, *scratch_bytes: the context owns it and frees it) and
+// grown when a call needs more: the first version made and freed seven allocations per call.
+hipError_t prf_lit_sort_unique(hipStream_t st, const prf_hit_dev *rows, u64 n, prf_hit_dev *out, u64 *n_out, void **scratch,
+                               size_t *scratch_bytes) {
     if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(u64), st);
     if (n > 0x7fffffffull) return hipErrorInvalidValue;
     const int ni = (int)n;
@@ -506,15 +509,24 @@ hipError_t prf_lit_sort_unique(hipStream_t st, const prf_hit_dev *rows, u64 n, p
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     step(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key_a, key_b, idx_a, idx_b, ni, 0, 64, st));
     step(hipcub::DeviceSelect::Flagged(nullptr, tmp_sel, sorted, first, out, n_out, ni, st));
-    const size_t tmp_bytes = tmp_sort > tmp_sel ? tmp_sort : tmp_sel;
-    step(hipMalloc((void **)&key_a, n * 8));
-    step(hipMalloc((void **)&key_b, n * 8));
-    step(hipMalloc((void **)&idx_a, n * 4));
-    step(hipMalloc((void **)&idx_b, n * 4));
-    step(hipMalloc((void **)&sorted, n * sizeof(prf_hit_dev)));
-    step(hipMalloc((void **)&first, n));
-    step(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    const size_t tmp_bytes = (tmp_sort > tmp_sel ? tmp_sort : tmp_sel) + 256;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_key_b = up(n * 8), o_idx_a = o_key_b + up(n * 8), o_idx_b = o_idx_a + up(n * 4), o_sorted = o_idx_b + up(n * 4),
+                 o_first = o_sorted + up(n * sizeof(prf_hit_dev)), o_tmp = o_first + up(n), total = o_tmp + tmp_bytes;
+    if (e == hipSuccess && total > *scratch_bytes) {
+        step(hipStreamSynchronize(st));  // nothing in flight may still use the old block
+        (void)hipFree(*scratch);
+        *scratch = nullptr;
+        *scratch_bytes = 0;
+        if (step(hipMalloc(scratch, total + total / 4))) *scratch_bytes = total + total / 4;
+    }
     if (e == hipSuccess) {
+        char *base = (char *)*scratch;
+        key_a = (u64 *)base; key_b = (u64 *)(base + o_key_b);
+        idx_a = (u32 *)(base + o_idx_a); idx_b = (u32 *)(base + o_idx_b);
+        sorted = (prf_hit_dev *)(base + o_sorted);
+        first = (unsigned char *)(base + o_first);
+        tmp = base + o_tmp;
         size_t b = tmp_bytes;
         hipLaunchKernelGGL(prf_lit_key_end_kernel, dim3(nb), dim3(256), 0, st, rows, n, key_a, idx_a);
         step(hipGetLastError());
@@ -527,10 +539,7 @@ hipError_t prf_lit_sort_unique(hipStream_t st, const prf_hit_dev *rows, u64 n, p
         step(hipGetLastError());
         b = tmp_bytes;
         step(hipcub::DeviceSelect::Flagged(tmp, b, sorted, first, out, n_out, ni, st));
-        step(hipStreamSynchronize(st));  // the scratch is freed below
     }
-    (void)hipFree(key_a); (void)hipFree(key_b); (void)hipFree(idx_a); (void)hipFree(idx_b);
-    (void)hipFree(sorted); (void)hipFree(first); (void)hipFree(tmp);
     return e;
 }
 

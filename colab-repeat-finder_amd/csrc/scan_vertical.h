@@ -10,7 +10,7 @@
 
 // Bit-sliced planes: see scan_vertical.hip for the layout.
 struct prf_vplanes {
-    u32 *VH = nullptr, *VL = nullptr, *VX = nullptr;
+    u32 *VH = nullptr, *VL = nullptr;     // (the not-ACGT plane exists in the linear layout only)
     unsigned char *tile_class = nullptr;  // per tile: 0 clean, 1 has not-ACGT positions in reach, 2 nothing but not-ACGT,
                                           // 3 a symbol outside ACGTN in reach (generic kernels)
     u32 *launch_list = nullptr;           // device: the tiles to scan in position order, PRF_LAUNCH_MIXED set on class-1 tiles
@@ -30,7 +30,7 @@ struct prf_vplanes {
 
 // everything the fused kernel needs (passed by value)
 struct prf_vscan_args {
-    const u32 *VH, *VL, *VX;       // bit-sliced planes
+    const u32 *VH, *VL;            // bit-sliced planes
     const u64 *H, *L, *X;          // linear planes (readable padding in front and behind)
     const u64 *const *E;           // device array of the five planes of the symbols outside ACGTN, or nullptr
     const u32 *launch_list;        // tiles in position order (PRF_LAUNCH_MIXED flags); one launch slot per entry

@@ -1258,13 +1258,18 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     set_prio(g.plan.prio & 3u);
     {
         sr.store(vimg, tid);
-        if (hasx && tid < 64) {  // AND of the 32 rows of the not-ACGT plane: bit b = stream (b, lane) is all N
-            const prf_u32x4 *px = reinterpret_cast<const prf_u32x4 *>(g.VX) + tile * (RG * 64);
-            prf_u32x4 v[RG];
-            static_for<0, RG>([&](auto rc) { v[decltype(rc)::value] = NextRegs<NC>::ld16(px, ((u32)decltype(rc)::value * 64u + (u32)tid) * 16u); });
-            prf_u32x4 a = v[0];
-            static_for<1, RG>([&](auto rc) { a &= v[decltype(rc)::value]; });
-            nostart[tid] = a.x & a.y & a.z & a.w;
+        if (hasx && tid < 64) {
+            // bit b = stream (b, lane) is all N: its 32 positions are one aligned dword of the LINEAR not-ACGT plane (round 3: the
+            // bit-sliced copy of that plane existed for this mask alone -- 0.125 B per position of HBM; mixed tiles are rare)
+            const u32 *px = reinterpret_cast<const u32 *>(g.X + tile * PRF_TILE_WORDS);
+            u32 m = 0;
+#pragma unroll 1
+            for (u32 b0 = 0; b0 < 32u; b0 += 8u) {  // (eight loads in flight: the registers of 32 would be spilled around this block)
+                u32 v[8];
+                static_for<0, 8>([&](auto bc) { v[decltype(bc)::value] = *(prf_glb_cu32 *)(px + ((b0 + (u32)decltype(bc)::value) * 64u + (u32)tid)); });
+                static_for<0, 8>([&](auto bc) { m |= (v[decltype(bc)::value] == ~0u ? 1u : 0u) << (b0 + (u32)decltype(bc)::value); });
+            }
+            nostart[tid] = m;
         }
         if (tid < 8) cnt[tid] = 0;  // rows, records, flags, ... (the other set is still read by slow waves)
         if (tid == 0) {  // the tile's part of the context (the rest was written once, above)
@@ -1727,7 +1732,7 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
 // ASCII -> bit-sliced planes.  One wave per tile; lane l, for bit b = 0..31, reads the 32 consecutive
 // bytes of stream b*64+l (a wave reads 2 KiB contiguous per b) and spreads them over its 32 row words.
 __global__ __launch_bounds__(64) void prf_pack_vertical_kernel(const uint8_t *__restrict__ asc, u32 *__restrict__ VH,
-                                                               u32 *__restrict__ VL, u32 *__restrict__ VX,
+                                                               u32 *__restrict__ VL,
                                                                unsigned char *__restrict__ any_all) {
     const u64 tile = blockIdx.x;
     const int lane = (int)threadIdx.x;
@@ -1758,12 +1763,10 @@ __global__ __launch_bounds__(64) void prf_pack_vertical_kernel(const uint8_t *__
     }
     uint4 *oh = reinterpret_cast<uint4 *>(VH) + tile * RG * 64 + lane;
     uint4 *ol = reinterpret_cast<uint4 *>(VL) + tile * RG * 64 + lane;
-    uint4 *ox = reinterpret_cast<uint4 *>(VX) + tile * RG * 64 + lane;
 #pragma unroll
     for (int rg = 0; rg < RG; rg++) {
         oh[rg * 64] = make_uint4(h[4 * rg], h[4 * rg + 1], h[4 * rg + 2], h[4 * rg + 3]);
         ol[rg * 64] = make_uint4(l[4 * rg], l[4 * rg + 1], l[4 * rg + 2], l[4 * rg + 3]);
-        ox[rg * 64] = make_uint4(x[4 * rg], x[4 * rg + 1], x[4 * rg + 2], x[4 * rg + 3]);
     }
     const bool w_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
     const bool w_all = __builtin_amdgcn_ballot_w64(all != ~0u) == 0;
@@ -1849,12 +1852,11 @@ int prf_vertical_pack(hipStream_t s, const uint8_t *asc, u64 G, prf_vplanes *vp)
     const size_t plane_bytes = (size_t)ntiles * RG * 64 * sizeof(uint4);
     if ((e = hipMalloc((void **)&vp->VH, plane_bytes)) != hipSuccess) return (int)e;
     if ((e = hipMalloc((void **)&vp->VL, plane_bytes)) != hipSuccess) return (int)e;
-    if ((e = hipMalloc((void **)&vp->VX, plane_bytes)) != hipSuccess) return (int)e;
     if ((e = hipMalloc((void **)&vp->tile_class, 2 * ntiles)) != hipSuccess) return (int)e;
     if ((e = hipMalloc((void **)&vp->launch_list, sizeof(u32) * ntiles)) != hipSuccess) return (int)e;
     vp->ntiles_alloc = ntiles;
     unsigned char *any_all = vp->tile_class + ntiles;
-    hipLaunchKernelGGL(prf_pack_vertical_kernel, dim3((u32)ntiles), dim3(64), 0, s, asc, vp->VH, vp->VL, vp->VX, any_all);
+    hipLaunchKernelGGL(prf_pack_vertical_kernel, dim3((u32)ntiles), dim3(64), 0, s, asc, vp->VH, vp->VL, any_all);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(prf_tile_class_kernel, dim3((u32)((ntiles + 255) / 256)), dim3(256), 0, s, any_all, vp->tile_class, ntiles);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

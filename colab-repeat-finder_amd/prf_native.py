@@ -65,7 +65,8 @@ EXPORTS = ["prf_abi_version", "prf_device_count", "prf_last_error", "prf_open", 
            "prf_measure_hbm_read", "prf_last_hits_to_device", "prf_plan_describe", "prf_fasta_open", "prf_fasta_count",
            "prf_fasta_entry", "prf_fasta_close", "prf_write_bed", "prf_write_tsv", "prf_genome_synth", "prf_scan_timings", "prf_set_row_sink", "prf_fasta_open_contig", "prf_scan_genome_async",
            "prf_scan_wait", "prf_genome_standin", "prf_genome_select", "prf_genome_tile_classes", "prf_tile_positions", "prf_scan_timings_split", "prf_last_hits_packed_to_device",
-           "prf_genome_contig_bases", "prf_scan_literal", "prf_scan_genome_async_packed", "prf_stream_wait_for"]
+           "prf_genome_contig_bases", "prf_scan_literal", "prf_scan_genome_async_packed", "prf_stream_wait_for",
+           "prf_genome_footprint"]
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -139,6 +140,7 @@ def load_library():
         lib.prf_set_row_sink.argtypes = [vp, vp, ctypes.c_uint64]
         lib.prf_last_hits_packed_to_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_genome_contig_bases.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.prf_genome_footprint.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_genome_async.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
         lib.prf_scan_genome_async_packed.argtypes = [vp, vp] + [ctypes.c_uint32] * 4 + [vp, ctypes.c_uint64, ctypes.c_uint64,
                                                                                          ctypes.POINTER(ctypes.c_uint64)]
@@ -251,6 +253,12 @@ class Genome:
         out = (ctypes.c_uint64 * max(1, n.value))()
         _check(self.ctx.lib, self.ctx.lib.prf_genome_contig_bases(self._h, out, n.value, ctypes.byref(n)))
         return np.array(out[:n.value], dtype=np.uint64)
+
+    def footprint(self):
+        """(device bytes the resident genome holds, positions of its coordinate space): prf_genome_footprint."""
+        b, n = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self.ctx.lib, self.ctx.lib.prf_genome_footprint(self._h, ctypes.byref(b), ctypes.byref(n)))
+        return b.value, n.value
 
     def scan_async(self, kmin, kmax, min_repeats, min_span):
         """Enqueue a scan (at most two in flight); returns its serial number for Context.scan_wait()."""

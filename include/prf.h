@@ -226,6 +226,11 @@ int prf_stream_wait_for(prf_ctx *ctx, void *other_stream);
 /* First position of every contig in the genome's coordinate space (multiples of prf_tile_positions()). */
 int prf_genome_contig_bases(const prf_genome *g, uint64_t *bases, uint64_t capacity, uint64_t *n_contigs);
 
+/* Device memory a resident genome holds (bytes: the packed planes in both layouts, tile tables, launch lists) and the positions
+ * of its coordinate space (contigs + guard gaps, what the planes cover).  Round 3: 0.625 bytes per position -- three linear
+ * planes (H, L, not-ACGT) and two bit-sliced ones; genomes with letters outside ACGTN add five linear planes. */
+int prf_genome_footprint(const prf_genome *g, uint64_t *device_bytes, uint64_t *positions);
+
 /* ---- the data formats either side of the path (host code, no GPU) ------------------------------------------
  * FASTA reader: what the reference takes from pyfastx.Fasta (perfect_repeat_finder.py:117,130,136-143): entries in
  * file order, name = header up to the first white space, sequence = the record's lines joined (case kept).

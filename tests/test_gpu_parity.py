@@ -996,6 +996,26 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
     assert st["algorithmic_bytes"] == (st["positions"] + 3) // 4 + 24 * st["rows"] and st["rows_sorted_on_device"] and st["scan_ms"] > 0
 
 
+def test_resident_genome_footprint(ctx):
+    """prf_genome_footprint: a resident genome of A, C, G, T, N holds 0.625 bytes per position of its coordinate space (three
+    linear planes, two bit-sliced ones) plus tables of a few bytes per 65 536 positions; letters outside ACGTN add five planes."""
+    import synth
+    seq = synth.chr_standin(length=3_000_000, seed=5, n_head=1000, n_tail=1000).tobytes()
+    g = ctx.load([seq, seq[:700_000]], 50)
+    try:
+        dev_bytes, positions = g.footprint()
+        assert positions % prf_native.tile_positions() == 0 and positions >= 3_700_000
+        assert 0.625 <= dev_bytes / positions < 0.64
+    finally:
+        g.free()
+    g = ctx.load([seq[:500_000] + b"RYK" + seq[500_000:900_000]], 50)
+    try:
+        dev_bytes, positions = g.footprint()
+        assert 1.25 <= dev_bytes / positions < 1.27
+    finally:
+        g.free()
+
+
 def test_randomised_differential_stress():
     """tools/stress_gpu.py for ~25 s: random multi-contig inputs x random parameter sets, GPU rows == oracle rows
     (a 240 s run of the same script covered 3 924 scans without a mismatch in round 1)."""
