@@ -999,6 +999,7 @@ def test_cli_fasta_and_literal_on_the_gpu(tmp_path, monkeypatch, capsys):
 def test_resident_genome_footprint(ctx):
     """prf_genome_footprint: a resident genome of A, C, G, T, N holds 0.625 bytes per position of its coordinate space (three
     linear planes, two bit-sliced ones) plus tables of a few bytes per 65 536 positions; letters outside ACGTN add five planes."""
+    import prf_native
     import synth
     seq = synth.chr_standin(length=3_000_000, seed=5, n_head=1000, n_tail=1000).tobytes()
     g = ctx.load([seq, seq[:700_000]], 50)

@@ -28,4 +28,7 @@ for w in ("hg38", "chr22", "chr1", "chr22-real"):
 json.dump(entries, open("profiles/pmc_traffic.json", "w"), indent=1)
 for f in glob.glob(f"{src}/bench_n1_*.json") + glob.glob(f"{src}/rehearsal_*.json"):
     shutil.copy(f, f"{dst}/{os.path.basename(f).replace('rehearsal_', 'rehearsal_gloo_one_gpu_')}")
+for f in ("stress_300s.txt", "pytest_gpu.log", "literal_timing.txt"):
+    if os.path.exists(f"{src}/{f}"):
+        shutil.copy(f"{src}/{f}", f"{dst}/{f}")
 print(json.dumps(entries, indent=1))
