@@ -156,7 +156,8 @@ int prf_scan(prf_ctx *ctx, const prf_contig *contigs, int n_contigs, uint32_t km
              uint32_t min_repeats, uint32_t min_span, uint32_t flags, prf_hits *out, prf_scan_stats *stats);
 
 /* The literal lane: the reference's per-tracker flush call (utils/perfect_repeat_tracker.py:71-101) evaluated as written,
- * one device thread per (position, motif size), on the upper-cased bytes of ONE sequence -- for the regimes outside the
+ * per (position, motif size) (round 3: a thread owns 64 positions and decides from bit masks which events can pass the
+ * filters at all; motif sizes above 63 one thread per four positions), on the upper-cased bytes of ONE sequence -- for the regimes outside the
  * closed form of the packed kernels: min_repeats == 1 (:86-91 then depend on the text in front of the run, on the slice
  * clamp at the end of the sequence and on Python's negative-index wrap-around), and a lock-step loop that stops early
  * (interval mode, reference perfect_repeat_finder.py:66-74).  `stop` = the number of iterations that loop performs
