@@ -1612,12 +1612,13 @@ __global__ __launch_bounds__(256) void prf_vgather_kernel(prf_vgather_args g) {
     u64 *dst = reinterpret_cast<u64 *>(g.rows + base0);
     // 256 rows per round: thread t decodes row r0 + t into three words in LDS, then the 768 words leave as coalesced stores; two
     // staging buffers used alternately, one barrier per round.  The slab rows of EIGHT rounds are fetched (slot search + load) in
-    // one batch in front of them.  gfx950 counts loads and stores on one counter and they complete out of order with respect to
-    // each other, so waiting for a load means waiting for every store issued before it: with a fetch per round every round
-    // ended with a full write round trip -- a workgroup of the default workload has 16 rounds, and 707 / 1 415 / 2 830 workgroups
-    // (32 / 16 / 8 rounds) took 66 / 49 / 60 us.  Now a workgroup waits for memory once per eight rounds: 47.5 us -- the kernel
-    // moves 183 MB in that time (3.9 TB/s, three quarters of it writes), so what is left is the copy itself.  (The rounds'
-    // barrier orders LDS only: s_waitcnt lgkmcnt(0) + s_barrier -- which is also all that __syncthreads() is on this target.)
+    // one batch in front of them.  gfx950 counts loads and stores on ONE counter, in issue order (MI355X_MICROARCH.md), so a load's
+    // data waits for every store issued before it -- and the compiler, once loads and stores are both in flight, waits for all of
+    // them (vmcnt(0)): with a fetch per round every round ended with a full write round trip.  Now a workgroup waits for memory
+    // once per eight rounds.  It bought 2 us of 49 on the default workload and costs 7 of 54 on ONE 10 Gbp sequence (a
+    // workgroup with two rounds of rows still searches for eight): the kernel moves 183 MB in its 47 us, of which ~22 us do
+    // not depend on the row count (profiles/r03_notes.md 2b).  (The rounds' barrier orders LDS only: s_waitcnt lgkmcnt(0) +
+    // s_barrier -- which is also all that __syncthreads() is on this target.)
     constexpr u32 DEPTH = 8;
     u32 buf = 0;
     for (u32 R = 0; R < n_copy; R += DEPTH * 256u) {  // (n_copy is uniform: every thread takes the same barriers)
