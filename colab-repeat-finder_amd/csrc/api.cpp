@@ -876,7 +876,7 @@ struct dev_free {
 };
 }  // namespace
 
-// d_seq: L bytes on the device (4-byte aligned, 16 readable bytes behind them); upper: not upper-cased / validated yet
+// d_seq: L bytes on the device (16-byte aligned: the 64-positions kernel reads whole 16-byte groups, 16 readable bytes behind them); upper: not upper-cased / validated yet
 static int literal_device(prf_ctx *c, uint8_t *d_seq, u64 L, bool upper, u32 contig_index, u32 kmin, u32 kmax, u32 min_repeats,
                           u32 min_span, u64 stop, std::vector<prf_hit> &rows_out, float *ms, u32 *launches, u64 pos_offset = 0) {
     if (stop > L) stop = L;
