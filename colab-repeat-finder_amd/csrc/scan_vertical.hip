@@ -1,5 +1,5 @@
 // scan_vertical.hip -- the fast path: fused bit-sliced ("vertical") scan + verification kernel for gfx950,
-// the row gather that follows it, the work planner and the ASCII -> bit-sliced packer.
+// the row gather that follows it and the ASCII -> bit-sliced packer (the work planner is host code: plan.cpp).
 //
 // What the kernels replace: the L x n_k calls of PerfectRepeatTracker.advance()
 // (reference utils/perfect_repeat_tracker.py:43-61), the per-run filter/emit step (:71-101, :108-142) and the
@@ -19,15 +19,18 @@
 //
 // One 256-thread workgroup per tile, SIX resident per CU (round 3; four before): <= 80 VGPRs and <= 27.3 KB of LDS.
 // What made room: ONE 18 KB region R1 is the bit-sliced image while the tile is scanned and the window of the linear
-// planes while its candidates are verified (before: two regions, 35 KB); both are filled by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write pass), the next tile's image while this tile's rows are
-// sorted; the exact tasks slide over the stream with a window of K + 4 rows in registers instead of all 60.
+// planes while its candidates are verified (before: two regions, 35 KB); the image arrives by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) while the previous tile's rows are sorted, the
+// window through the registers of the two waves that finish their tasks first; the exact tasks slide over the stream
+// with a window of K + 4 rows in registers instead of all 60.
 //  1. stage: the image arrived by DMA; 128 threads add the virtual lanes 64.. (one shift/or of two prefetched slots).
 //  2. scan: every wave runs its share of the plan's tasks (host-built, balanced by cost).  A task answers one
 //     question per (stream, motif size): "may a reportable run be found from this stream?" --
-//      * exact task, one motif size k <= 14 with M(k) = M < 15 (compiled per (k, M)): mismatch word per row
+//      * exact task, one motif size k with M(k) = M <= 8 (compiled per (k, M)): mismatch word per row
 //        (2 operations), sliding OR over exactly M rows; a row whose M successors all match and whose predecessor
 //        does not is the start of a run of >= M.
+//      * coarse task, one motif size with 9 <= M <= 14: the same on aligned groups of 2 or 4 rows (a run of >= M rows
+//        holds floor((M + 1) / G) - 1 consecutive all-match groups).
 //      * group task, 8 motif sizes k0..k0+7 with M(k) >= 15: a run of >= 15 matches contains an aligned
 //        group of 8 rows that all match.  Per (group, k) the 8 rows of (H^H')|(L^L') are OR-ed with 16
 //        v_bitop3_b32; motif sizes with M >= 23 / 39 examine only every 2nd / 4th group.
