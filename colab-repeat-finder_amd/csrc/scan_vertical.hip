@@ -95,6 +95,8 @@ using prf_layout::SMEM_HDR;
 constexpr int HDR_CNT = 128;       // [parity][8] u32
 constexpr int HDR_NEXT = 192;      // {next launch slot, its entry}
 constexpr int HDR_LONG = 200;      // [PRF_LONG_PER_TILE] u64: true ends of the rows whose span is clipped
+constexpr int HDR_STATS = 232;     // {candidates looked at, of which verified on the spot} by this workgroup so far (thread 0's)
+static_assert(HDR_LONG + 8 * (int)PRF_LONG_PER_TILE <= HDR_STATS && HDR_STATS + 8 <= SMEM_HDR, "LDS header layout");
 constexpr u32 CNT_ROWS = 0, CNT_RECS = 1, CNT_EARLY = 2, CNT_LONG = 3, CNT_FLAGS = 4, CNT_SLOW = 5,
               CNT_ROWS0 = 6, CNT_LONG0 = 7;  // rows / long rows listed before the verification began (the scan's overflow paths)
 
@@ -595,8 +597,9 @@ __device__ __forceinline__ prf_lds_u32 *smem_cnt(u32 parity) { return (prf_lds_u
 //  * exact tasks left ONE ballot-compacted list of (stream, task) flags in LDS, dealt to the threads from thread 0 up;
 //  * group-task records (one list) are taken by the upper two waves, alternately; the boundary items by the lower half, from
 //    its last thread down.
+template <class Mid>
 __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems, const unsigned short __attribute__((address_space(3))) *flags,
-                                           u32 n_flags, const u32 *xw, u32 tid, u64 *dbg) {
+                                           u32 n_flags, const u32 *xw, u32 tid, u64 *dbg, Mid &&between_flags_and_boundary_items) {
 #ifdef PRF_STAMPS
 #define PRF_VSTAMP(i) do { if (dbg && (tid & 63u) == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -640,6 +643,7 @@ __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_l
             else defer(tc, tc.tile_base, k, 0u, 1u, 0u, 0ull);
         }
         PRF_VSTAMP(14);
+        between_flags_and_boundary_items();  // (the kernel's hook: the next tile's launch-list entry is fetched here)
         // ---- boundary items: from the half's last thread down (the last round of flags fills it from the first thread up)
         for (u32 idx = (u32)NTH / 2u - 1u - tid; idx < n_bitems; idx += (u32)NTH / 2u) {
             const u32 it = bitems[idx];
@@ -785,7 +789,9 @@ __device__ __forceinline__ prf_lds_cu4 *slot_after(prf_lds_cu4 *first, int a) {
 template <int NC, bool S1, bool HALF>
 __device__ __forceinline__ void group_task(prf_lds_cu4 *vimg, int lane, u32 k0, u32 valid, u32 stride, u32 allow, Emit &em) {
     constexpr int PS = RG * NC;  // slots per plane
-    prf_lds_cu4 *lane_base = vimg + lane;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (the address is recomputed here: hoisted out of the task loop it was kept in scratch memory)
+    prf_lds_cu4 *lane_base = vimg + lane_o;
     u32 prev[8], acc[8];
     static_for<0, 8>([&](auto ic) {
         prev[decltype(ic)::value] = ~0u;  // first group of a stream: counts, verification decides
@@ -880,7 +886,9 @@ __device__ __attribute__((noinline)) u32 exact_stream(prf_lds_cu4 *vimg, int lan
     constexpr int NM = T + M - 1;            // mismatch words of rows 0 .. NM-1
     constexpr int NG = (NM + K + 3) / 4;     // 16-byte slots of rows read
     static_assert(4 * NG <= 2 * T, "an exact task reads its own lane and the next one");
-    prf_lds_cu4 *lane_base = vimg + lane;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (the address is recomputed here: hoisted out of the task loop it was kept in scratch memory)
+    prf_lds_cu4 *lane_base = vimg + lane_o;
     u32 r0[4 * NG], r1[4 * NG];
     u32 mm[NM + 1];
     u32 o3[NM + 1];
@@ -954,7 +962,9 @@ __device__ __attribute__((noinline)) u32 coarse_stream(prf_lds_cu4 *vimg, int la
     constexpr int NR = T + G * C;                   // mismatch rows -G .. NR - 1
     constexpr int NG = (NR + K + 3) / 4;            // 16-byte slots of rows read
     static_assert(C >= 2 && 4 * NG <= 2 * T, "a coarse task reads its own lane and the next one");
-    prf_lds_cu4 *lane_base = vimg + lane;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (the address is recomputed here: hoisted out of the task loop it was kept in scratch memory)
+    prf_lds_cu4 *lane_base = vimg + lane_o;
     // rows -4 .. -1: the last slot of the previous stream, (lane-1, b); for lane 0 that is stream (63, b-1): lane 63's words one
     // bit up, with bit 0 (the previous tile's last stream) unknown -> "mismatch", verification decides
     u32 q0[4], q1[4];
@@ -1059,6 +1069,12 @@ template <int NC>
 __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, const prf_vplan &plan, int wave, int lane, bool relax, u32 allow,
                                           Emit &em, u64 *dbg) {
     const u32 t_end = plan.wave_begin[wave + 1];
+    {   // (opaque: the exact tasks are functions, and a callee that knows the image's address as a constant looks the dynamic LDS
+        // base up in a table in memory on every call -- handed over as an argument it is a register)
+        u32 a = (u32)(__UINTPTR_TYPE__)vimg;
+        asm volatile("" : "+s"(a));
+        vimg = (prf_lds_cu4 *)(__UINTPTR_TYPE__)a;
+    }
 #ifdef PRF_STAMPS
     u64 t_call = 0;
 #endif
@@ -1232,19 +1248,26 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     // Launch slots are handed out dynamically (tiles differ in cost by a factor of three; a fixed stride leaves the last
     // workgroups running alone for 8 % of the scan): XCD x -- the workgroups b = x mod 8 -- takes the slots = x mod 8, the
     // first one per workgroup by index, the following ones by a ticket counter of its own (one atomic per tile on eight
-    // separate words; the ticket is drawn at the top of a tile and needed at its end).
+    // separate words; the ticket is drawn behind the tile's scan and needed at its end).
     const u32 xcd = blockIdx.x & 7u;
     const u32 first_ticket = (gridDim.x - xcd + 7u) >> 3;  // workgroups of this XCD = slots taken without a ticket
     u64 *ticket_word = g.counters + (PRF_CNT_SHARD0 + xcd * PRF_CNT_SHARD_STRIDE + PRF_SH_TILE_TICKET);
     prf_lds_u32 *next_words = (prf_lds_u32 *)(prf_smem + HDR_NEXT);  // {next slot, its launch-list entry}
     u32 slot_next = 0;
     u32 parity = 0;
-    u64 cand_total = 0;  // (thread 0) candidates looked at by this workgroup: ONE atomic when it ends
-    u64 early_total = 0; // ... of which verified on the spot by the general routine because a list was full
+    // (thread 0) candidates looked at by this workgroup, and those verified on the spot by the general routine because a list was
+    // full: ONE atomic each when the workgroup ends.  Kept in LDS: as registers they lived in scratch memory across the tile
+    // loop -- two scratch loads and two stores per tile in front of wave 0's verification.
+    prf_lds_u32 *wg_stats = (prf_lds_u32 *)(prf_smem + HDR_STATS);
+    if (tid0 == 0) wg_stats[0] = wg_stats[1] = 0;
     for (u32 slot = blockIdx.x; slot < g.n_launch; slot = slot_next, parity ^= 1u) {
     // (opaque per round: what derives from the thread index is recomputed, not carried through the scan's calls in
     // registers that would have to be spilled)
-    int tid = tid0;
+    int wave_s = wave;
+    asm volatile("" : "+s"(wave_s));  // (opaque: recomputed from a scalar and the hardware's lane index, two operations)
+    u32 ones = ~0u;
+    asm volatile("" : "+s"(ones));  // (opaque too: the lane index is not to be computed once and kept in scratch memory either)
+    int tid = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const u32 entry = sr.entry;
@@ -1289,12 +1312,6 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     PRF_STAMP(1);
     __syncthreads();  // (waits for the image's DMA too)
     PRF_STAMP(2);
-    // the ticket for the tile after this one: drawn here, first used behind the scan (round 3: the file is built with the
-    // compiler's atomic optimizer off -- it turned this one-lane returning atomic into a wave-aggregated one and waited for its
-    // value on the spot, 3 k cycles in front of the ticket wave's tasks; now the value is back long before it is looked at).
-    u64 ticket = 0;
-    const bool ticket_thread = tid == (int)(g.plan.ticket_wave * 64u);  // (the plan's least loaded wave)
-    if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
 
     // ---- 2. scan ----
     set_prio(((g.plan.slack_waves >> wave) & 1u) ? (g.plan.prio >> 4) & 3u : (g.plan.prio >> 2) & 3u);
@@ -1366,15 +1383,23 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             cnt[CNT_LONG0] = cnt[CNT_LONG];
         }
     }
-    // the next launch slot and its entry (a load from the launch list unless the list is one run of clean tiles): issued here,
-    // needed behind the verification
-    u32 slot_pre = 0, entry_pre = entry;
-    if (ticket_thread) {
-        slot_pre = (first_ticket + (u32)ticket) * 8u + xcd;
-        if (slot_pre < g.n_launch) entry_pre = entry_of(slot_pre);  // (last round: this tile again, unused)
-    }
     __syncthreads();
     PRF_STAMP(4);
+    // The ticket for the tile after this one is drawn HERE: from here to the end of the tile this wave calls nothing.  (Drawn at
+    // the top of the tile -- the first version -- its value was waited for at once all the same: a function waits for every
+    // outstanding memory operation on entry, and the first task is a call; and kept across the tasks' calls it lived in scratch
+    // memory.)  The launch-list entry of the slot it names is fetched between the flags and the boundary items, both are
+    // handed to the workgroup behind the verification.
+    u64 ticket = 0;
+    const bool ticket_thread = tid == 64;  // (a thread of the lower half: its waves finish the verification first in most tiles)
+    if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
+    u32 slot_pre = 0, entry_pre = entry;
+    auto fetch_next_entry = [&]() {
+        if (ticket_thread) {
+            slot_pre = (first_ticket + (u32)ticket) * 8u + xcd;
+            if (slot_pre < g.n_launch) entry_pre = entry_of(slot_pre);  // (last round: this tile again, unused)
+        }
+    };
 
     // ---- 3b. verify, all waves together: every candidate -> a row in the tile's list, or nothing ----
     // (the record waves are the critical path of this phase, the flag waves wait for them at the barrier below)
@@ -1385,8 +1410,9 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
     {
         if (tid == 0) {
             // statistics: candidates looked at = (stream, exact task) flags + group-task records (+ those verified on the spot)
-            cand_total += n_flags + n_recs + cnt[CNT_EARLY];
-            early_total += cnt[CNT_EARLY];
+            const u32 early = cnt[CNT_EARLY];
+            wg_stats[0] += n_flags + n_recs + early;
+            wg_stats[1] += early;
         }
         n_recs = n_recs < (u32)REC_CAP ? n_recs : (u32)REC_CAP;
         n_flags = n_flags < (u32)FLAG_CAP ? n_flags : (u32)FLAG_CAP;
@@ -1395,7 +1421,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
 #endif
         if (g.skip & 2u) n_flags = 0;   // (diagnostic) the flags are listed but not verified
         if (g.skip & 4u) n_recs = 0;    // (diagnostic) the same for the records
-        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
+        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg, fetch_next_entry);
     }
     set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
@@ -1543,10 +1569,11 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
 #endif
     // (no barrier here: the next round's first barrier separates this tile's reads of the row list from the next tile's writes)
     }
-    if (tid0 == 0 && cand_total)
-        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], cand_total);
-    if (tid0 == 0 && early_total)
-        atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_EARLY], early_total);
+    if (tid0 == 0) {
+        const u64 cand_total = wg_stats[0], early_total = wg_stats[1];
+        if (cand_total) atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_CAND], cand_total);
+        if (early_total) atomicAdd(&g.counters[PRF_CNT_SHARD0 + (blockIdx.x % PRF_CNT_NSHARD) * PRF_CNT_SHARD_STRIDE + PRF_SH_EARLY], early_total);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
