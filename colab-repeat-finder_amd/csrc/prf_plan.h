@@ -16,7 +16,7 @@ typedef unsigned int u32;
 // One unit of scan work for one wave on one tile.
 //  kind 0     : "group" task -- the 8 motif sizes k0 .. k0+7 (k0 % 4 == 0) selected by `valid`, all with M(k) >= 15
 //  kind 1..14 : "exact" task -- the single motif size k0 (<= 14), whose minimum run length M(k0) equals `kind`
-struct prf_vtask {
+struct alignas(4) prf_vtask {   // (two dwords: the kernel reads a task with one scalar load)
     unsigned short k0;
     unsigned char kind;
     unsigned char valid;

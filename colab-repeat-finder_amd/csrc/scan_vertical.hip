@@ -597,9 +597,8 @@ __device__ __forceinline__ prf_lds_u32 *smem_cnt(u32 parity) { return (prf_lds_u
 //  * exact tasks left ONE ballot-compacted list of (stream, task) flags in LDS, dealt to the threads from thread 0 up;
 //  * group-task records (one list) are taken by the upper two waves, alternately; the boundary items by the lower half, from
 //    its last thread down.
-template <class Mid>
 __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_lds_cu32 *bitems, u32 n_bitems, const unsigned short __attribute__((address_space(3))) *flags,
-                                           u32 n_flags, const u32 *xw, u32 tid, u64 *dbg, Mid &&between_flags_and_boundary_items) {
+                                           u32 n_flags, const u32 *xw, u32 tid, u64 *dbg) {
 #ifdef PRF_STAMPS
 #define PRF_VSTAMP(i) do { if (dbg && (tid & 63u) == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -643,7 +642,6 @@ __device__ __forceinline__ void verify_all(prf_lds_cu64 *recs, u32 n_recs, prf_l
             else defer(tc, tc.tile_base, k, 0u, 1u, 0u, 0ull);
         }
         PRF_VSTAMP(14);
-        between_flags_and_boundary_items();  // (the kernel's hook: the next tile's launch-list entry is fetched here)
         // ---- boundary items: from the half's last thread down (the last round of flags fills it from the first thread up)
         for (u32 idx = (u32)NTH / 2u - 1u - tid; idx < n_bitems; idx += (u32)NTH / 2u) {
             const u32 it = bitems[idx];
@@ -1079,7 +1077,18 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, 
     u64 t_call = 0;
 #endif
     for (u32 ti = plan.wave_begin[wave]; ti < t_end; ti++) {
-        const prf_vtask task = plan.tasks[ti];
+        // (the task as two dwords, decoded by hand: left to the compiler the one-byte fields came by vector loads from the kernel's
+        // arguments -- a global-memory round trip, waited for on the spot, in front of every group task)
+        static_assert(sizeof(prf_vtask) == 8 && alignof(prf_vtask) == 4, "a task is read as two dwords");
+        const u32 *tw = reinterpret_cast<const u32 *>(&plan.tasks[ti]);
+        const u32 tw0 = (u32)__builtin_amdgcn_readfirstlane((int)tw[0]), tw1 = (u32)__builtin_amdgcn_readfirstlane((int)tw[1]);
+        prf_vtask task;
+        task.k0 = (unsigned short)(tw0 & 0xFFFFu);
+        task.kind = (unsigned char)((tw0 >> 16) & 0xFFu);
+        task.valid = (unsigned char)(tw0 >> 24);
+        task.stride = (unsigned char)(tw1 & 0xFFu);
+        task.pad = 0;
+        task.item0 = (unsigned short)(tw1 >> 16);
 #ifdef PRF_STAMPS
         if (dbg && lane == 0 && ti - plan.wave_begin[wave] < 8u) dbg[8 + (ti - plan.wave_begin[wave])] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1359,6 +1368,14 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             });
         }
     }
+    // The ticket for the tile after this one is drawn by the wave that leaves the scan first, behind its window loads: it waits for
+    // those at the barrier below anyway, and the atomic's round trip is no longer than theirs.  (Drawn at the top of the tile -- the
+    // first version -- the value was waited for at once all the same: a function waits for every outstanding memory operation on
+    // entry, and the first task is a call; kept across the tasks' calls it lived in scratch memory.  Drawn behind the scan by a
+    // fixed thread it was waited for on the spot as well, by a wave with work to do.)
+    u64 ticket = 0;
+    const bool ticket_thread = order == 0u && lane == 0;
+    if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
     PRF_STAMP(3);
     __syncthreads();  // the image is dead from here on
     {
@@ -1383,23 +1400,15 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
             cnt[CNT_LONG0] = cnt[CNT_LONG];
         }
     }
+    // The next launch slot's entry (a load from the launch list unless the list is one run of clean tiles): issued here by the
+    // thread that drew the ticket, looked at behind the verification.
+    u32 slot_pre = 0, entry_pre = entry;
+    if (ticket_thread) {
+        slot_pre = (first_ticket + (u32)ticket) * 8u + xcd;
+        if (slot_pre < g.n_launch) entry_pre = entry_of(slot_pre);  // (last round: this tile again, unused)
+    }
     __syncthreads();
     PRF_STAMP(4);
-    // The ticket for the tile after this one is drawn HERE: from here to the end of the tile this wave calls nothing.  (Drawn at
-    // the top of the tile -- the first version -- its value was waited for at once all the same: a function waits for every
-    // outstanding memory operation on entry, and the first task is a call; and kept across the tasks' calls it lived in scratch
-    // memory.)  The launch-list entry of the slot it names is fetched between the flags and the boundary items, both are
-    // handed to the workgroup behind the verification.
-    u64 ticket = 0;
-    const bool ticket_thread = tid == 64;  // (a thread of the lower half: its waves finish the verification first in most tiles)
-    if (ticket_thread) ticket = atomicAdd(ticket_word, 1ull);
-    u32 slot_pre = 0, entry_pre = entry;
-    auto fetch_next_entry = [&]() {
-        if (ticket_thread) {
-            slot_pre = (first_ticket + (u32)ticket) * 8u + xcd;
-            if (slot_pre < g.n_launch) entry_pre = entry_of(slot_pre);  // (last round: this tile again, unused)
-        }
-    };
 
     // ---- 3b. verify, all waves together: every candidate -> a row in the tile's list, or nothing ----
     // (the record waves are the critical path of this phase, the flag waves wait for them at the barrier below)
@@ -1421,7 +1430,7 @@ __global__ __launch_bounds__(NTH, 6) void prf_vscan_kernel(prf_vscan_args g) {
 #endif
         if (g.skip & 2u) n_flags = 0;   // (diagnostic) the flags are listed but not verified
         if (g.skip & 4u) n_recs = 0;    // (diagnostic) the same for the records
-        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg, fetch_next_entry);
+        verify_all((prf_lds_cu64 *)recs, n_recs, (prf_lds_cu32 *)bitems, (g.skip & 8u) ? 0u : g.plan.n_group_k, (prf_lds_cu16 *)hotw, n_flags, xw, (u32)tid, task_dbg);
     }
     set_prio((g.plan.prio >> 10) & 3u);
     if (ticket_thread) {  // the next slot and its entry, for everybody behind the barrier
