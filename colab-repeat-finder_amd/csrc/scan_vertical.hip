@@ -1119,6 +1119,9 @@ __device__ __forceinline__ void run_tasks(prf_lds_cu4 *vimg, prf_lds_u32 *hotw, 
 }
 
 __device__ __forceinline__ void set_prio(u32 p) {  // (s_setprio takes an immediate; p is wave-uniform)
+#ifdef PRF_NO_PRIO  // (diagnostic: what the priorities and the branches that select them cost)
+    return;
+#endif
     if (p == 0u) __builtin_amdgcn_s_setprio(0);
     else if (p == 1u) __builtin_amdgcn_s_setprio(1);
     else if (p == 2u) __builtin_amdgcn_s_setprio(2);
